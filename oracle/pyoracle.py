@@ -1,0 +1,193 @@
+"""ctypes binding of oracle/librvo_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Importers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Intrinsics(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("depth_width", C.c_int32),
+                ("depth_height", C.c_int32)] + [(n, C.c_double) for n in
+                                                ("fx", "fy", "cx", "cy", "k1", "k2", "k3", "p1", "p2")]
+
+
+class Params(C.Structure):
+    _fields_ = [("feature_window_size", C.c_int32), ("num_pyramid_levels", C.c_int32),
+                ("fast_init_threshold", C.c_int32), ("fast_threshold_min", C.c_int32),
+                ("fast_threshold_max", C.c_int32), ("fast_adaptive_gain", C.c_double),
+                ("target_pixels_per_feature", C.c_int32), ("grid_width", C.c_int32),
+                ("grid_height", C.c_int32), ("max_keypoints_per_grid", C.c_int32),
+                ("inlier_max_reprojection_error", C.c_double), ("clique_inlier_threshold", C.c_double),
+                ("min_features_for_estimate", C.c_int32), ("max_mean_reprojection_error", C.c_double),
+                ("feature_search_window", C.c_double), ("reference_frame_change_threshold", C.c_int32),
+                ("warmup_frames", C.c_int32)]
+
+
+class PairResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 12), ("cov", C.c_double * 36), ("status", C.c_int32),
+                ("num_matches", C.c_int32), ("num_inliers", C.c_int32),
+                ("num_reprojection_failures", C.c_int32), ("mean_reprojection_error", C.c_double)]
+
+
+def default_params(frame_matcher: bool = False, **over) -> Params:
+    """settings.hpp:11-52 defaults (VO: keyframe threshold 250, FrameMatcher: 150)."""
+    p = Params(9, 3, 20, 5, 70, 0.005, 250, 80, 80, 25, 1.5, 0.1, 10, 10.0, 25.0,
+               150 if frame_matcher else 250, 100)
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def make_intrinsics(d: dict) -> Intrinsics:
+    return Intrinsics(**{k: d[k] for k, _ in Intrinsics._fields_})
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "librvo_oracle.so")
+    src = os.path.join(_HERE, "rvo_oracle.cpp")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(Intrinsics), C.POINTER(Params)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_vo_create.restype = C.c_void_p
+        L.orc_vo_create.argtypes = [C.c_void_p, C.c_int]
+        L.orc_vo_destroy.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, intr: dict, params: Params | None = None):
+        self.L = lib()
+        self.intr = make_intrinsics(intr)
+        self.params = params or default_params()
+        self.h = C.c_void_p(self.L.orc_create(C.byref(self.intr), C.byref(self.params)))
+        self.W, self.H = intr["width"], intr["height"]
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def lut(self):
+        x = np.empty((self.H, self.W), np.float32)
+        y = np.empty((self.H, self.W), np.float32)
+        self.L.orc_get_lut(self.h, _p(x), _p(y))
+        return x, y
+
+    def prepare(self, slot: int, gray: np.ndarray, depth: np.ndarray, thr: int):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        self.L.orc_prepare_frame(self.h, C.c_int(slot), _p(gray), _p(depth), C.c_int(thr))
+
+    def level_info(self, slot, level):
+        o = np.zeros(6, np.int32)
+        self.L.orc_level_info(self.h, C.c_int(slot), C.c_int(level), _p(o))
+        return dict(width=int(o[0]), height=int(o[1]), stride=int(o[2]), num_keypoints=int(o[3]),
+                    num_detected=int(o[4]), num_after_grid=int(o[5]))
+
+    def level_image(self, slot, level):
+        i = self.level_info(slot, level)
+        out = np.empty((i["height"], i["stride"]), np.uint8)
+        self.L.orc_level_image(self.h, C.c_int(slot), C.c_int(level), _p(out))
+        return out[:, :i["width"]]
+
+    def grid_keypoints(self, slot, level):
+        i = self.level_info(slot, level)
+        out = np.empty((i["num_after_grid"], 3), np.float32)
+        self.L.orc_level_grid_keypoints(self.h, C.c_int(slot), C.c_int(level), _p(out))
+        return out
+
+    def keypoints(self, slot, level):
+        n = self.level_info(slot, level)["num_keypoints"]
+        uvs = np.empty((n, 3), np.float32)
+        rect = np.empty((n, 2), np.float64)
+        xyz = np.empty((n, 3), np.float64)
+        self.L.orc_level_keypoints(self.h, C.c_int(slot), C.c_int(level), _p(uvs), _p(rect), _p(xyz))
+        return uvs, rect, xyz
+
+    def descriptors(self, slot, level):
+        n = self.level_info(slot, level)["num_keypoints"]
+        st = self.L.orc_descriptor_stride(self.h)
+        out = np.empty((n, st), np.uint8)
+        self.L.orc_level_descriptors(self.h, C.c_int(slot), C.c_int(level), _p(out))
+        return out
+
+    def initial_rotation(self, prev_slot, cur_slot):
+        q = np.zeros(4)
+        self.L.orc_initial_rotation(self.h, C.c_int(prev_slot), C.c_int(cur_slot), _p(q))
+        return q
+
+    def estimate_motion(self, ref_slot, tgt_slot, init3x4):
+        r = PairResult()
+        init = np.ascontiguousarray(init3x4, np.float64).reshape(12)
+        self.L.orc_estimate_motion(self.h, C.c_int(ref_slot), C.c_int(tgt_slot), _p(init), C.byref(r))
+        return result_to_dict(r)
+
+    def match_pair(self, ref_slot, tgt_slot):
+        r = PairResult()
+        self.L.orc_match_pair(self.h, C.c_int(ref_slot), C.c_int(tgt_slot), C.byref(r))
+        return result_to_dict(r)
+
+    def matches(self, n):
+        ints = np.zeros((n, 7), np.int32)
+        dbl = np.zeros((n, 8), np.float64)
+        self.L.orc_get_matches(self.h, _p(ints), _p(dbl))
+        return ints, dbl
+
+
+class OracleVO:
+    """RGBDVO::ProcessFrame (vo.cpp:55-165) on the oracle, one stream."""
+
+    def __init__(self, oracle: Oracle, base_slot: int = 0):
+        self.o = oracle
+        self.h = C.c_void_p(oracle.L.orc_vo_create(oracle.h, C.c_int(base_slot)))
+
+    def process(self, gray, depth):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        oi = np.zeros(6, np.int32)
+        od = np.zeros(24, np.float64)
+        rc = self.o.L.orc_vo_process(self.h, _p(gray), _p(depth), _p(oi), _p(od))
+        return dict(rc=int(rc), fast_thr=int(oi[1]), keyframe_changed=bool(oi[2]), status=int(oi[3]),
+                    num_inliers=int(oi[4]), num_matches=int(oi[5]), pose=od[:12].reshape(3, 4).copy(),
+                    curr_to_ref=od[12:].reshape(3, 4).copy())
+
+    def close(self):
+        if self.h:
+            self.o.L.orc_vo_destroy(self.h)
+            self.h = None
+
+
+def result_to_dict(r: PairResult) -> dict:
+    return dict(pose=np.array(r.pose).reshape(3, 4), cov=np.array(r.cov).reshape(6, 6), status=int(r.status),
+                num_matches=int(r.num_matches), num_inliers=int(r.num_inliers),
+                num_reprojection_failures=int(r.num_reprojection_failures),
+                mean_reprojection_error=float(r.mean_reprojection_error))
