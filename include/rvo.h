@@ -1,0 +1,169 @@
+/* rvo.h -- C ABI of librgbdvo_hip.so: the MI355X (gfx950) implementation of the
+ * rgbdvo per-frame odometry front-end of alanzplus/SLAM.
+ *
+ * The reference has no FFI layer; its boundary is the C++ class API of
+ * librgbdvo.  This C ABI is what the C++ facade in
+ * include/rgbdvo/ (RGBDVO, FrameMatcher, Camera, Options) sits on, and what
+ * tests/bench bind through ctypes.  Each entry point cites the reference
+ * interface it replaces (paths relative to /root/reference/).
+ *
+ * Conventions: every function returns 0 on success or a negative RVO_E_* code;
+ * nothing throws or calls exit() across the ABI.  The context owns all device
+ * memory.  One context per (device, host thread); a context is not thread-safe.
+ * Work is enqueued on the context's HIP stream; functions that return results to
+ * host memory synchronise that stream, the *_async / *_dev forms do not.
+ * Poses are 3x4 row-major [R|t] doubles, covariances 6x6 row-major doubles
+ * (symmetric, so equal to Eigen's column-major layout).
+ */
+#ifndef RVO_H_
+#define RVO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVO_MAX_LEVELS 6
+
+enum {
+  RVO_OK = 0,
+  RVO_E_INVALID = -1,     /* bad argument (null pointer, slot/pair index out of range, n > capacity) */
+  RVO_E_UNSUPPORTED = -2, /* option value this build does not implement (e.g. feature-window-size != 9) */
+  RVO_E_HIP = -3,         /* a HIP runtime call failed; rvo_last_error() has the text */
+  RVO_E_NOMEM = -4
+};
+
+/* rgbdvo/camera.hpp:11-49 IntrinsicParameters (h_fov/v_fov are unused by the path) */
+typedef struct rvo_intrinsics {
+  int32_t width, height, depth_width, depth_height;
+  double fx, fy, cx, cy, k1, k2, k3, p1, p2;
+} rvo_intrinsics;
+
+/* rgbdvo/settings.hpp:11-52 option keys, parsed (rgbdvo/helper.cpp:13-59).  warmup_frames is
+ * the hard-coded 100 of rgbdvo/vo.cpp:58. */
+typedef struct rvo_params {
+  int32_t feature_window_size;
+  int32_t num_pyramid_levels;
+  int32_t fast_init_threshold;
+  int32_t fast_threshold_min;
+  int32_t fast_threshold_max;
+  double fast_adaptive_gain;
+  int32_t target_pixels_per_feature;
+  int32_t grid_width;
+  int32_t grid_height;
+  int32_t max_keypoints_per_grid;
+  double inlier_max_reprojection_error;
+  double clique_inlier_threshold;
+  int32_t min_features_for_estimate;
+  double max_mean_reprojection_error;
+  double feature_search_window;
+  int32_t reference_frame_change_threshold;
+  int32_t warmup_frames;
+} rvo_params;
+
+/* rgbdvo/motion_estimate.hpp:13-20 MotionEstimateStatusCode */
+enum { RVO_NO_DATA = 0, RVO_SUCCESS = 1, RVO_INSUFFICIENT_INLIERS = 2, RVO_OPTIMIZATION_FAILURE = 3, RVO_REPROJECTION_ERROR = 4 };
+/* rgbdvo/feature.hpp:188-201 MatchStatusCode */
+enum { RVO_MATCH_NEEDS_DEPTH_REFINEMENT = 0, RVO_MATCH_REFINEMENT_FAILED = 1, RVO_MATCH_OK = 2 };
+
+/* What MotionEstimator exposes after EstimateMotion (rgbdvo/motion_estimate.hpp:40-74). */
+typedef struct rvo_pair_result {
+  double pose[12];
+  double cov[36];
+  int32_t status;
+  int32_t num_matches;
+  int32_t num_inliers;
+  int32_t num_reprojection_failures;
+  double mean_reprojection_error;
+} rvo_pair_result;
+
+/* Per-stream output of one ProcessFrame step (rgbdvo/vo.hpp:22-45 getters). */
+typedef struct rvo_stream_result {
+  double pose[12];         /* GetPose() */
+  double curr_to_ref[12];  /* GetCurrToRefMotionEstimate() */
+  double cov[36];          /* GetCurrToRefCov() */
+  int32_t rc;              /* 0 = warm-up frame skipped, 1 = processed, -1 = both estimates failed
+                              (where the reference calls exit(-1), rgbdvo/vo.cpp:154-158) */
+  int32_t fast_threshold;  /* adaptive FAST threshold after this frame (rgbdvo/vo.cpp:92-99) */
+  int32_t keyframe_changed;/* IsKeyFrameChanged() */
+  int32_t status;          /* last EstimateMotion status */
+  int32_t num_matches, num_inliers;
+  int32_t used_fallback;   /* 1 if the estimate came from the retry vs the previous frame (vo.cpp:131-152) */
+  int32_t pad_;
+} rvo_stream_result;
+
+typedef struct rvo_ctx rvo_ctx;
+
+/* settings.hpp:11-30 GetRGBDVODefaultOptions() / :33-52 GetFrameMatcherDefaultOptions() */
+void rvo_default_vo_params(rvo_params* out);
+void rvo_default_fm_params(rvo_params* out);
+
+/* Replaces the constructors RGBDVO::RGBDVO (rgbdvo/vo.cpp:22-47) and FrameMatcher::FrameMatcher
+ * (rgbdvo/fm.cpp:6-20): builds the undistortion LUT (Camera::MakeXYMap, rgbdvo/camera.cpp:16-67) on the host,
+ * uploads it and allocates `max_frames` frame slots and `max_pairs` pair work areas on `device`. */
+int rvo_create(const rvo_intrinsics* intr, const rvo_params* params, int device, int max_frames, int max_pairs,
+               rvo_ctx** out);
+void rvo_destroy(rvo_ctx* ctx);
+const char* rvo_last_error(void);
+
+/* Use an existing HIP stream (hipStream_t passed as void*; NULL = the context's own). */
+int rvo_set_stream(rvo_ctx* ctx, void* hip_stream);
+int rvo_sync(rvo_ctx* ctx);
+
+/* Frame::PrepareFrame (rgbdvo/frame.cpp:37-158) incl. the depth conversion of rgbdvo/vo.cpp:83-87 for
+ * n frames: gray is n tightly packed W*H u8 images, depth n tightly packed Wd*Hd u16 images
+ * (millimetres, 0 = invalid), fast_thr[n] the FAST threshold per frame, slots[n] the destination
+ * frame slots.  Host-buffer form (copies H2D, then runs, then synchronises). */
+int rvo_prepare_frames(rvo_ctx* ctx, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* fast_thr,
+                       const int32_t* slots);
+/* Same, gray/depth already in device memory; enqueues only (no synchronisation). */
+int rvo_prepare_frames_dev(rvo_ctx* ctx, int n, const uint8_t* gray_dev, const uint16_t* depth_dev,
+                           const int32_t* fast_thr, const int32_t* slots);
+
+/* FrameMatcher::Match (rgbdvo/fm.cpp:32-58) on prepared slots, for n independent pairs:
+ * EstimateInitialRotation (rgbdvo/motion_estimate.cpp:268-304) + EstimateMotion (:149-243).
+ * init_pose = NULL -> initial estimate is identity rotated by the initial-rotation estimate (fm.cpp:41-47);
+ * otherwise n 3x4 poses used as EstimateMotion's init_motion_est directly (no initial rotation).
+ * out may be NULL for the _async form; fetch later with rvo_get_pair_results. */
+int rvo_match_pairs(rvo_ctx* ctx, int n, const int32_t* ref_slots, const int32_t* tgt_slots, const double* init_pose,
+                    rvo_pair_result* out);
+int rvo_match_pairs_async(rvo_ctx* ctx, int n, const int32_t* ref_slots, const int32_t* tgt_slots,
+                          const double* init_pose);
+int rvo_get_pair_results(rvo_ctx* ctx, int n, rvo_pair_result* out);
+/* EstimateInitialRotation alone: q[n][4] = (w,x,y,z) */
+int rvo_initial_rotation(rvo_ctx* ctx, int n, const int32_t* prev_slots, const int32_t* cur_slots, double* q_wxyz);
+
+/* Streaming: n_streams independent RGBDVO instances (rgbdvo/vo.cpp:55-165 state machine each) living in
+ * slots [3*s, 3*s+3).  rvo_streams_reset = constructor + SetInitPose(identity) (rgbdvo/vo.hpp:42-45). */
+int rvo_streams_reset(rvo_ctx* ctx, int n_streams);
+int rvo_stream_step(rvo_ctx* ctx, int n_streams, const uint8_t* gray, const uint16_t* depth, rvo_stream_result* out);
+int rvo_stream_step_dev(rvo_ctx* ctx, int n_streams, const uint8_t* gray_dev, const uint16_t* depth_dev);
+int rvo_get_stream_results(rvo_ctx* ctx, int n_streams, rvo_stream_result* out);
+/* Device pointer to the stream-result array (for a device-side trajectory buffer / RCCL gather). */
+int rvo_stream_results_dev(rvo_ctx* ctx, void** dev_ptr);
+
+/* ---- per-stage dump accessors (parity tests; the inspection surface of rgbdvo/pyramid.hpp:62-151 and
+ * rgbdvo/motion_estimate.hpp:56-74) ---- */
+/* info[6] = width,height,stride,num_keypoints,num_detected(after NMS),num_after_grid */
+int rvo_get_level_info(rvo_ctx* ctx, int slot, int level, int32_t* info);
+int rvo_get_level_image(rvo_ctx* ctx, int slot, int level, uint8_t* out /* height*stride */);
+int rvo_get_grid_keypoints(rvo_ctx* ctx, int slot, int level, float* uvs /* [n][3] u,v,score */);
+int rvo_get_keypoints(rvo_ctx* ctx, int slot, int level, float* uvs /* [n][3] */, double* rect /* [n][2] */,
+                      double* xyz /* [n][3] */);
+int rvo_get_descriptors(rvo_ctx* ctx, int slot, int level, uint8_t* out /* [n][80] */);
+/* matches of pair `pair` from the last rvo_match_pairs, in the reference's post-sort order:
+ * ints[n][7] = ref_idx,tgt_idx,level,status,inlier,id,degree; dbl[n][8] = refined u,v, rect u,v, xyz, reproj error */
+int rvo_get_matches(rvo_ctx* ctx, int pair, int32_t* ints, double* dbl);
+int rvo_get_lut(rvo_ctx* ctx, float* xmap, float* ymap);
+
+/* ---- measurement support ---- */
+/* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
+int rvo_profile_enable(rvo_ctx* ctx, int on);
+/* names/ms/calls arrays of capacity cap; returns the number of kernel kinds (accumulated since enable). */
+int rvo_profile_read(rvo_ctx* ctx, int cap, const char** names, float* total_ms, int32_t* calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVO_H_ */

@@ -1,0 +1,279 @@
+"""Python mirror of the rgbdvo API on top of the C ABI (include/rvo.h).
+
+`Context` is the batched engine (frame slots + pair work areas on one GPU);
+`FrameMatcher` mirrors rgbdvo::FrameMatcher (/root/reference/rgbdvo/fm.hpp:14-44) and
+`RGBDVOStreams` mirrors N independent rgbdvo::RGBDVO instances
+(/root/reference/rgbdvo/vo.hpp:15-102).  All compute happens in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Intrinsics, PairResult, Params, StreamResult
+
+STATUS_NAMES = ["NO_DATA", "SUCCESS", "INSUFFICIENT_INLIERS", "OPTIMIZATION_FAILURE", "REPROJECTION_ERROR"]
+
+
+class RvoError(RuntimeError):
+    pass
+
+
+def default_params(frame_matcher: bool = False, **over) -> Params:
+    """GetRGBDVODefaultOptions / GetFrameMatcherDefaultOptions (settings.hpp:11-52)."""
+    p = Params()
+    L = _lib.load()
+    (L.rvo_default_fm_params if frame_matcher else L.rvo_default_vo_params)(C.byref(p))
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+def params_from_options(options: dict, frame_matcher: bool = False) -> Params:
+    """Parse a reference-style string map (settings.hpp keys, helper.cpp:13-59 stoi/stod)."""
+    p = default_params(frame_matcher)
+    for key, val in options.items():
+        name = key.replace("-", "_")
+        if name == "min_feature_for_estimate":
+            name = "min_features_for_estimate"
+        if name == "feature_search_window":
+            p.feature_search_window = float(val)
+            continue
+        if not hasattr(p, name):
+            raise KeyError(f"unknown option {key!r}")
+        cur = getattr(p, name)
+        setattr(p, name, float(val) if isinstance(cur, float) else int(val))
+    return p
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+class Context:
+    def __init__(self, intr: dict, params: Params | None = None, max_frames: int = 8, max_pairs: int = 4,
+                 device: int = 0):
+        self.L = _lib.load()
+        self.intr = Intrinsics(**{k: intr[k] for k, _ in Intrinsics._fields_})
+        self.params = params or default_params()
+        self.W, self.H = intr["width"], intr["height"]
+        self.Wd, self.Hd = intr["depth_width"], intr["depth_height"]
+        self.levels = self.params.num_pyramid_levels
+        self.max_frames, self.max_pairs = max_frames, max_pairs
+        h = C.c_void_p()
+        self._chk(self.L.rvo_create(C.byref(self.intr), C.byref(self.params), device, max_frames, max_pairs,
+                                    C.byref(h)))
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RvoError(f"rvo error {rc}: {self.L.rvo_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rvo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: int):
+        self._chk(self.L.rvo_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def sync(self):
+        self._chk(self.L.rvo_sync(self.h))
+
+    # -- frames
+    def prepare_frames(self, gray, depth, fast_thr, slots):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        slots = _i32(slots)
+        n = len(slots)
+        thr = _i32(np.broadcast_to(np.asarray(fast_thr, np.int32), (n,)))
+        assert gray.size == n * self.W * self.H and depth.size == n * self.Wd * self.Hd
+        self._chk(self.L.rvo_prepare_frames(self.h, n, _ptr(gray), _ptr(depth), _ptr(thr), _ptr(slots)))
+
+    def prepare_frames_dev(self, gray_ptr: int, depth_ptr: int, fast_thr, slots):
+        slots = _i32(slots)
+        n = len(slots)
+        thr = _i32(np.broadcast_to(np.asarray(fast_thr, np.int32), (n,)))
+        self._chk(self.L.rvo_prepare_frames_dev(self.h, n, C.c_void_p(gray_ptr), C.c_void_p(depth_ptr), _ptr(thr),
+                                                _ptr(slots)))
+
+    # -- pairs
+    def match_pairs(self, ref_slots, tgt_slots, init_pose=None):
+        ref_slots, tgt_slots = _i32(ref_slots), _i32(tgt_slots)
+        n = len(ref_slots)
+        out = (PairResult * n)()
+        ip = None if init_pose is None else np.ascontiguousarray(init_pose, np.float64).reshape(n, 12)
+        self._chk(self.L.rvo_match_pairs(self.h, n, _ptr(ref_slots), _ptr(tgt_slots), _ptr(ip), out))
+        return [pair_result_to_dict(r) for r in out]
+
+    def match_pairs_async(self, ref_slots, tgt_slots, init_pose=None):
+        ref_slots, tgt_slots = _i32(ref_slots), _i32(tgt_slots)
+        n = len(ref_slots)
+        ip = None if init_pose is None else np.ascontiguousarray(init_pose, np.float64).reshape(n, 12)
+        self._chk(self.L.rvo_match_pairs_async(self.h, n, _ptr(ref_slots), _ptr(tgt_slots), _ptr(ip)))
+
+    def pair_results(self, n):
+        out = (PairResult * n)()
+        self._chk(self.L.rvo_get_pair_results(self.h, n, out))
+        return [pair_result_to_dict(r) for r in out]
+
+    def initial_rotation(self, prev_slots, cur_slots):
+        prev_slots, cur_slots = _i32(prev_slots), _i32(cur_slots)
+        q = np.zeros((len(prev_slots), 4))
+        self._chk(self.L.rvo_initial_rotation(self.h, len(prev_slots), _ptr(prev_slots), _ptr(cur_slots), _ptr(q)))
+        return q
+
+    # -- inspection
+    def level_info(self, slot, level):
+        o = np.zeros(6, np.int32)
+        self._chk(self.L.rvo_get_level_info(self.h, slot, level, _ptr(o)))
+        return dict(width=int(o[0]), height=int(o[1]), stride=int(o[2]), num_keypoints=int(o[3]),
+                    num_detected=int(o[4]), num_after_grid=int(o[5]))
+
+    def level_image(self, slot, level):
+        i = self.level_info(slot, level)
+        out = np.empty((i["height"], i["stride"]), np.uint8)
+        self._chk(self.L.rvo_get_level_image(self.h, slot, level, _ptr(out)))
+        return out[:, :i["width"]]
+
+    def grid_keypoints(self, slot, level):
+        n = self.level_info(slot, level)["num_after_grid"]
+        out = np.empty((n, 3), np.float32)
+        self._chk(self.L.rvo_get_grid_keypoints(self.h, slot, level, _ptr(out)))
+        return out
+
+    def keypoints(self, slot, level):
+        n = self.level_info(slot, level)["num_keypoints"]
+        uvs = np.empty((n, 3), np.float32)
+        rect = np.empty((n, 2), np.float64)
+        xyz = np.empty((n, 3), np.float64)
+        self._chk(self.L.rvo_get_keypoints(self.h, slot, level, _ptr(uvs), _ptr(rect), _ptr(xyz)))
+        return uvs, rect, xyz
+
+    def descriptors(self, slot, level):
+        n = self.level_info(slot, level)["num_keypoints"]
+        out = np.empty((n, 80), np.uint8)
+        self._chk(self.L.rvo_get_descriptors(self.h, slot, level, _ptr(out)))
+        return out
+
+    def matches(self, pair, n):
+        ints = np.zeros((n, 7), np.int32)
+        dbl = np.zeros((n, 8), np.float64)
+        self._chk(self.L.rvo_get_matches(self.h, pair, _ptr(ints), _ptr(dbl)))
+        return ints, dbl
+
+    def lut(self):
+        x = np.empty((self.H, self.W), np.float32)
+        y = np.empty((self.H, self.W), np.float32)
+        self._chk(self.L.rvo_get_lut(self.h, _ptr(x), _ptr(y)))
+        return x, y
+
+    # -- streams
+    def streams_reset(self, n_streams):
+        self._chk(self.L.rvo_streams_reset(self.h, n_streams))
+
+    def stream_step(self, gray, depth, n_streams):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        out = (StreamResult * n_streams)()
+        self._chk(self.L.rvo_stream_step(self.h, n_streams, _ptr(gray), _ptr(depth), out))
+        return [stream_result_to_dict(r) for r in out]
+
+    def stream_step_dev(self, gray_ptr: int, depth_ptr: int, n_streams):
+        self._chk(self.L.rvo_stream_step_dev(self.h, n_streams, C.c_void_p(gray_ptr), C.c_void_p(depth_ptr)))
+
+    def stream_results(self, n_streams):
+        out = (StreamResult * n_streams)()
+        self._chk(self.L.rvo_get_stream_results(self.h, n_streams, out))
+        return [stream_result_to_dict(r) for r in out]
+
+    def stream_results_dev_ptr(self) -> int:
+        p = C.c_void_p()
+        self._chk(self.L.rvo_stream_results_dev(self.h, C.byref(p)))
+        return p.value
+
+    # -- profiling
+    def profile_enable(self, on=True):
+        self._chk(self.L.rvo_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        calls = (C.c_int32 * cap)()
+        n = self.L.rvo_profile_read(self.h, cap, names, ms, calls)
+        if n < 0:
+            self._chk(n)
+        return {names[i].decode(): dict(total_ms=float(ms[i]), calls=int(calls[i])) for i in range(min(n, cap))}
+
+
+def pair_result_to_dict(r: PairResult) -> dict:
+    return dict(pose=np.array(r.pose).reshape(3, 4), cov=np.array(r.cov).reshape(6, 6), status=int(r.status),
+                num_matches=int(r.num_matches), num_inliers=int(r.num_inliers),
+                num_reprojection_failures=int(r.num_reprojection_failures),
+                mean_reprojection_error=float(r.mean_reprojection_error))
+
+
+def stream_result_to_dict(r: StreamResult) -> dict:
+    return dict(pose=np.array(r.pose).reshape(3, 4), curr_to_ref=np.array(r.curr_to_ref).reshape(3, 4),
+                cov=np.array(r.cov).reshape(6, 6), rc=int(r.rc), fast_thr=int(r.fast_threshold),
+                keyframe_changed=bool(r.keyframe_changed), status=int(r.status), num_matches=int(r.num_matches),
+                num_inliers=int(r.num_inliers), used_fallback=bool(r.used_fallback))
+
+
+class FrameMatcher:
+    """rgbdvo::FrameMatcher (fm.hpp:14-44) at batch size 1: SetRefFrame / Match / GetMotionEstimate / GetCov."""
+
+    def __init__(self, intr: dict, options: dict | None = None, device: int = 0):
+        self.ctx = Context(intr, params_from_options(options or {}, frame_matcher=True), max_frames=2, max_pairs=1,
+                           device=device)
+        self.thr = self.ctx.params.fast_init_threshold
+        self.result = None
+
+    def SetRefFrame(self, gray, raw_depth):  # fm.cpp:22-30
+        self.ctx.prepare_frames(gray, raw_depth, self.thr, [0])
+
+    def Match(self, gray, raw_depth) -> bool:  # fm.cpp:32-58
+        self.ctx.prepare_frames(gray, raw_depth, self.thr, [1])
+        self.result = self.ctx.match_pairs([0], [1])[0]
+        return self.result["status"] == 1
+
+    def GetMotionEstimate(self):
+        m = np.eye(4)
+        m[:3] = self.result["pose"]
+        return m
+
+    def GetCov(self):
+        return self.result["cov"]
+
+
+class RGBDVOStreams:
+    """N independent rgbdvo::RGBDVO instances (vo.hpp:15-102) advanced in lock-step on one GPU."""
+
+    def __init__(self, intr: dict, n_streams: int, options: dict | None = None, device: int = 0, params: Params | None = None):
+        p = params or params_from_options(options or {})
+        self.n = n_streams
+        self.ctx = Context(intr, p, max_frames=3 * n_streams, max_pairs=n_streams, device=device)
+        self.ctx.streams_reset(n_streams)
+
+    def ProcessFrame(self, gray, raw_depth):
+        """gray [n,H,W] u8, raw_depth [n,Hd,Wd] u16 -> list of per-stream result dicts."""
+        return self.ctx.stream_step(gray, raw_depth, self.n)

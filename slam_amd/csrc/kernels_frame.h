@@ -1,0 +1,369 @@
+// kernels_frame.h -- Frame::PrepareFrame on the GPU (rgbdvo/frame.cpp:37-158):
+//   k_pyr_down        GaussPyramid::BuildNextLevel            pyramid.cpp:53-99
+//   k_fast_grid       FAST + NMS + GridKeyPointFilter         feature.cpp:6058-6077, pyramid.cpp:15-51
+//   k_build_keypoints border/LUT/depth filter, descriptors,   frame.cpp:92-147, feature.cpp:6140-6207,
+//                     back-projection                          depth.cpp:48-78
+// All integer/byte stages are bit-exact restatements; see DESIGN.md for the layouts.
+#pragma once
+#include "rvo_dev.h"
+#include "stdalgo.h"
+
+// ------------------------------------------------------------------ helpers
+__device__ inline int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// exclusive scan of one int per thread over a 256-thread block; *total = block sum.
+// s_wave must hold 4 ints.  Contains two barriers.
+__device__ inline int block_excl_scan_256(int v, int* s_wave, int* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int n = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += n;
+  }
+  __syncthreads();  // protect s_wave from the previous call's readers
+  if (lane == 63) s_wave[wid] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    int t = s_wave[w];
+    if (w < wid) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+// ------------------------------------------------------------------ pyramid
+#define PYR_TW 64
+#define PYR_TH 16
+#define PYR_SROWS (2 * PYR_TH + 3)   // 35
+#define PYR_SCOLS (2 * PYR_TW + 8)   // 136 bytes loaded per row, from 2*ox0-4
+
+// One tap set of HorizontalGaussFilter (pyramid.cpp:67-99): output index r of a line of n samples.
+template <class F>
+__device__ inline int gauss_tap(F at, int n, int r) {
+  const int last = n / 2 - 1;
+  if (r == 0) return (at(0) + 4 * at(1) + 3 * at(2)) >> 3;
+  if (r < last) return (at(2 * r - 2) + 4 * at(2 * r - 1) + 6 * at(2 * r) + 4 * at(2 * r + 1) + at(2 * r + 2)) >> 4;
+  const int o = 2 * (last - 1);
+  if (n & 1) return (3 * at(o) + 4 * at(o + 1) + at(o + 2)) >> 3;
+  return (at(o) + 4 * at(o + 1) + 7 * at(o + 2) + 4 * at(o + 3)) >> 4;
+}
+
+// grid (ceil(dw/64), ceil(dh/16), n_frames); both truncating passes fused through LDS.
+__global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots, int lvl) {
+  const LevelGeom S = g.lv[lvl - 1], D = g.lv[lvl];
+  const int slot = slots[blockIdx.z];
+  const uint8_t* __restrict__ src = fb.img + (size_t)slot * g.img_bytes + S.img_off;
+  uint8_t* __restrict__ dst = fb.img + (size_t)slot * g.img_bytes + D.img_off;
+  const int dw = S.w / 2, dh = S.h / 2;
+  const int ox0 = blockIdx.x * PYR_TW, oy0 = blockIdx.y * PYR_TH;
+  const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
+  __shared__ __align__(16) uint8_t s_src[PYR_SROWS][PYR_SCOLS];
+  __shared__ uint8_t s_mid[PYR_SROWS][PYR_TW];
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < PYR_SROWS * (PYR_SCOLS / 4); i += 256) {
+    const int r = i / (PYR_SCOLS / 4), c4 = i % (PYR_SCOLS / 4);
+    const int gy = sy0 + r, gx = sx0 + 4 * c4;
+    uint32_t v = 0;
+    if (gy >= 0 && gy < S.h) {
+      const uint8_t* row = src + (size_t)gy * S.stride;
+      if (gx >= 0 && gx + 3 < S.stride) {
+        v = *reinterpret_cast<const uint32_t*>(row + gx);
+      } else {
+        for (int k = 0; k < 4; k++)
+          if (gx + k >= 0 && gx + k < S.stride) v |= (uint32_t)row[gx + k] << (8 * k);
+      }
+    }
+    *reinterpret_cast<uint32_t*>(&s_src[r][4 * c4]) = v;
+  }
+  __syncthreads();
+  // pass 1: along x (source rows -> s_mid), what the reference stores transposed in pyrbuf
+  for (int i = tid; i < PYR_SROWS * PYR_TW; i += 256) {
+    const int r = i / PYR_TW, x = i % PYR_TW;
+    const int gy = sy0 + r, ox = ox0 + x;
+    int v = 0;
+    if (gy >= 0 && gy < S.h && ox < dw) {
+      const uint8_t* row = s_src[r];
+      v = gauss_tap([&](int k) { return (int)row[k - sx0]; }, S.w, ox);
+    }
+    s_mid[r][x] = (uint8_t)v;
+  }
+  __syncthreads();
+  // pass 2: along y
+  const int x = tid & 63;
+  for (int y = tid >> 6; y < PYR_TH; y += 4) {
+    const int ox = ox0 + x, oy = oy0 + y;
+    if (ox < dw && oy < dh) {
+      int v = gauss_tap([&](int k) { return (int)s_mid[k - sy0][x]; }, S.h, oy);
+      dst[(size_t)oy * D.stride + ox] = (uint8_t)v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ FAST-9
+// 9 contiguous set bits in a cyclic 16-bit mask
+__device__ inline bool has9(uint32_t m) {
+  uint32_t d = m | (m << 16);
+  uint32_t r = d & (d >> 1);
+  r &= r >> 2;
+  r &= r >> 4;
+  r &= d >> 8;
+  return (r & 0xFFFFu) != 0;
+}
+
+// Segment test of fast9Detect (feature.cpp:3033-5953; equivalence with the generated tree is checked
+// exhaustively by oracle/check_fast_tree.py) and fast9CornerScore (feature.cpp:67-2995): the binary
+// search returns the largest b for which the test passes = A-1, A = max over the 16 nine-arcs of the
+// arc's min |difference| with a consistent sign.  Returns 0 (no corner at threshold b) or score+1 = A.
+__device__ inline int fast9_score_plus1(const uint8_t* t, int pitch, int b) {
+  const int p = t[0];
+  int d[16];
+  d[0] = t[3 * pitch] - p;       d[1] = t[3 * pitch + 1] - p;   d[2] = t[2 * pitch + 2] - p;   d[3] = t[pitch + 3] - p;
+  d[4] = t[3] - p;               d[5] = t[-pitch + 3] - p;      d[6] = t[-2 * pitch + 2] - p;  d[7] = t[-3 * pitch + 1] - p;
+  d[8] = t[-3 * pitch] - p;      d[9] = t[-3 * pitch - 1] - p;  d[10] = t[-2 * pitch - 2] - p; d[11] = t[-pitch - 3] - p;
+  d[12] = t[-3] - p;             d[13] = t[pitch - 3] - p;      d[14] = t[2 * pitch - 2] - p;  d[15] = t[3 * pitch - 1] - p;
+  uint32_t br = 0, dk = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    br |= (uint32_t)(d[i] > b) << i;
+    dk |= (uint32_t)(d[i] < -b) << i;
+  }
+  if (!(has9(br) || has9(dk))) return 0;
+  int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+  for (int i = 0; i < 16; i++) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
+  int best_lo = -256, best_hi = 256;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
+    int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
+    best_lo = max(best_lo, lo9);
+    best_hi = min(best_hi, hi9);
+  }
+  return max(best_lo, -best_hi);
+}
+
+struct FastLds {  // byte offsets into dynamic LDS, computed on the host (all multiples of 4)
+  int tile_pitch, score_pitch;
+  int off_score, off_list, off_misc;
+  int list_cap;
+  int total;
+};
+
+// grid (total_buckets, n_frames), 256 threads: one workgroup per 80x80 grid cell.  The cell plus a
+// 4-px halo is staged in LDS once; FAST scores are computed for the cell plus a 1-px halo; NMS
+// (feature.cpp:5960-6056, non-strict: an equal neighbour suppresses) runs on the LDS score tile; the
+// survivors are compacted in raster order (the order the reference pushes them into the bucket) and
+// one lane replays libstdc++'s nth_element when the bucket exceeds max-keypoints-per-grid.
+__global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, FastLds L, const int32_t* __restrict__ slots,
+                                                   const int32_t* __restrict__ thr) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint8_t* s_tile = lds;
+  uint8_t* s_score = lds + L.off_score;
+  uint32_t* s_list = reinterpret_cast<uint32_t*>(lds + L.off_list);
+  int* s_misc = reinterpret_cast<int*>(lds + L.off_misc);  // [0..3] wave sums
+
+  const int tid = threadIdx.x;
+  const int slot = slots[blockIdx.y];
+  const int b = thr[blockIdx.y];
+  int lvl = 0;
+  const int gb = blockIdx.x;  // bucket index within the slot
+#pragma unroll
+  for (int l = 1; l < RVO_MAX_LEVELS; l++)
+    if (l < g.levels && gb >= g.lv[l].bucket_off) lvl = l;
+  const LevelGeom G = g.lv[lvl];
+  const int bi = gb - G.bucket_off;
+  const int cx0 = (bi % G.gcols) * g.gw, cy0 = (bi / G.gcols) * g.gh;
+  const int cw = min(g.gw, G.w - cx0), ch = min(g.gh, G.h - cy0);
+  const uint8_t* __restrict__ img = fb.img + (size_t)slot * g.img_bytes + G.img_off;
+  const int TP = L.tile_pitch, SP = L.score_pitch;
+
+  // ---- stage cell + 4 px halo
+  const int trows = ch + 8, tdw = TP / 4;
+  const int gx0 = cx0 - 4, gy0 = cy0 - 4;
+  const bool aligned = (gx0 & 3) == 0;
+  for (int i = tid; i < trows * tdw; i += 256) {
+    const int r = i / tdw, c4 = i % tdw;
+    const int gy = gy0 + r, gx = gx0 + 4 * c4;
+    uint32_t v = 0;
+    if (gy >= 0 && gy < G.h) {
+      const uint8_t* row = img + (size_t)gy * G.stride;
+      if (aligned && gx >= 0 && gx + 3 < G.stride) {
+        v = *reinterpret_cast<const uint32_t*>(row + gx);
+      } else {
+        for (int k = 0; k < 4; k++)
+          if (gx + k >= 0 && gx + k < G.stride) v |= (uint32_t)row[gx + k] << (8 * k);
+      }
+    }
+    *reinterpret_cast<uint32_t*>(s_tile + r * TP + 4 * c4) = v;
+  }
+  __syncthreads();
+
+  // ---- FAST score for the cell + 1 px halo (0 = not a corner, else score+1)
+  const int sw = cw + 2, sh = ch + 2;
+  for (int i = tid; i < sw * sh; i += 256) {
+    const int sy = i / sw, sx = i % sw;           // score-tile coords; cell pixel = (sx-1, sy-1)
+    const int gx = cx0 + sx - 1, gy = cy0 + sy - 1;
+    int s = 0;
+    if (gx >= 3 && gx <= G.w - 4 && gy >= 3 && gy <= G.h - 4)   // fast9Detect loop bounds, feature.cpp:3042-3043
+      s = fast9_score_plus1(s_tile + (sy + 3) * TP + (sx + 3), TP, b);
+    s_score[sy * SP + sx] = (uint8_t)s;
+  }
+  __syncthreads();
+
+  // ---- NMS + raster-ordered compaction
+  const int P = cw * ch;
+  const int per = (P + 255) / 256;
+  const int i0 = min(P, tid * per), i1 = min(P, i0 + per);
+  auto survives = [&](int idx) -> int {
+    const int y = idx / cw, x = idx % cw;
+    const uint8_t* c = s_score + (y + 1) * SP + (x + 1);
+    const int s = c[0];
+    if (s == 0) return 0;
+    if (c[-1] >= s || c[1] >= s) return 0;
+    if (c[-SP - 1] >= s || c[-SP] >= s || c[-SP + 1] >= s) return 0;
+    if (c[SP - 1] >= s || c[SP] >= s || c[SP + 1] >= s) return 0;
+    return s;
+  };
+  int cnt = 0;
+  for (int i = i0; i < i1; i++) cnt += survives(i) != 0;
+  int total;
+  int pos = block_excl_scan_256(cnt, s_misc, &total);
+  for (int i = i0; i < i1; i++) {
+    const int s = survives(i);
+    if (s) {
+      if (pos < L.list_cap) s_list[pos] = kp_pack(cx0 + i % cw, cy0 + i / cw, s - 1);
+      pos++;
+    }
+  }
+  __syncthreads();
+
+  // ---- GridKeyPointFilter::Filter for this bucket (pyramid.cpp:38-50)
+  const int n = min(total, L.list_cap);
+  const int maxp = g.max_per;
+  if (n > maxp && tid == 0)
+    stdalgo::nth_element(s_list, maxp, n, [](uint32_t l, uint32_t r) { return kp_s(l) > kp_s(r); });
+  __syncthreads();
+  const int keep = min(n, maxp);
+  uint32_t* out = fb.bk_kp + ((size_t)slot * g.total_buckets + gb) * maxp;
+  for (int i = tid; i < keep; i += 256) out[i] = s_list[i];
+  if (tid == 0) {
+    fb.bk_cnt[(size_t)slot * g.total_buckets + gb] = keep;
+    fb.bk_det[(size_t)slot * g.total_buckets + gb] = total;
+  }
+}
+
+// ------------------------------------------------------------------ keypoint records + descriptors + XYZ
+// grid (levels, n_frames), 256 threads.
+__global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots) {
+  __shared__ int s_wave[4];
+  __shared__ int s_red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lvl = blockIdx.x;
+  const int slot = slots[blockIdx.y];
+  const LevelGeom G = g.lv[lvl];
+  const uint8_t* __restrict__ img = fb.img + (size_t)slot * g.img_bytes + G.img_off;
+  const uint16_t* __restrict__ depth = fb.depth + (size_t)slot * g.Wd * g.Hd;
+  const int32_t* bk_cnt = fb.bk_cnt + (size_t)slot * g.total_buckets + G.bucket_off;
+  const int32_t* bk_det = fb.bk_det + (size_t)slot * g.total_buckets + G.bucket_off;
+  const uint32_t* bk_kp = fb.bk_kp + ((size_t)slot * g.total_buckets + G.bucket_off) * g.max_per;
+  const size_t kbase = (size_t)slot * g.kp_total + G.kp_off;
+
+  // level totals (num_detected_keypoints_, frame.cpp:76-77)
+  int det = 0, kept = 0;
+  for (int i = tid; i < G.nbuckets; i += 256) { det += bk_det[i]; kept += bk_cnt[i]; }
+  det = wave_sum(det);
+  kept = wave_sum(kept);
+  if (lane == 0) { s_red[wid] = det; s_red[4 + wid] = kept; }
+  __syncthreads();
+  if (tid == 0) {
+    fb.det_cnt[slot * RVO_MAX_LEVELS + lvl] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    fb.grid_cnt[slot * RVO_MAX_LEVELS + lvl] = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+  }
+
+  // frame.cpp:92-142
+  const int mde = (RVO_WIN - 1) / 2 + 1;
+  const int min_x = mde, min_y = mde, max_x = G.w - (mde + 1), max_y = G.h - (mde + 1);
+  const int nslots = G.nbuckets * g.max_per;
+  int base = 0;
+  for (int c0 = 0; c0 < nslots; c0 += 256) {
+    const int s = c0 + tid;
+    int flag = 0;
+    uint32_t k = 0;
+    float ru = 0.f, rv = 0.f;
+    double X = 0, Y = 0, Z = 0;
+    if (s < nslots) {
+      const int bk = s / g.max_per, j = s % g.max_per;
+      if (j < bk_cnt[bk]) {
+        k = bk_kp[s];
+        const int x = kp_x(k), y = kp_y(k);
+        if (!(x < min_x || x > max_x || y < min_y || y > max_y)) {
+          const int idx = (y << lvl) * g.W + (x << lvl);
+          ru = fb.xmap[idx];
+          rv = fb.ymap[idx];
+          if (!(ru < 0 || ru >= (float)g.W || rv < 0 || rv >= (float)g.H)) {
+            const int du = (int)((double)ru + 0.5), dv = (int)((double)rv + 0.5);
+            // Depth::RGB2DepthIdx, depth.hpp:41-43
+            const int di = (int)((double)dv * (double)g.ys) * g.Wd + (int)((double)du * (double)g.xs);
+            const uint16_t d = depth[di];
+            if (d) {  // HaveXYZ: d ? d*1e-3 : NaN
+              flag = 1;
+              const double z = (double)(float)((double)d * 1e-3);
+              const double rx = (double)du * g.fx_inv + g.neg_cx_div_fx;
+              const double ry = (double)dv * g.fy_inv + g.neg_cy_div_fy;
+              X = z * rx; Y = z * ry; Z = z;
+            }
+          }
+        }
+      }
+    }
+    int total;
+    const int pos = base + block_excl_scan_256(flag, s_wave, &total);
+    if (flag) {
+      fb.kp_uvs[kbase + pos] = k;
+      fb.kp_rect[kbase + pos] = make_float2(ru, rv);
+      double* xyz = fb.kp_xyz + (kbase + pos) * 3;
+      xyz[0] = X; xyz[1] = Y; xyz[2] = Z;
+    }
+    base += total;
+  }
+  if (tid == 0) fb.kp_cnt[slot * RVO_MAX_LEVELS + lvl] = base;
+  __syncthreads();  // kp_uvs written by this block are re-read below (same workgroup: L1-coherent after barrier)
+  __threadfence_block();
+
+  // descriptors: one wave per keypoint; ExtractAlignedDescriptor + Normalized twice (feature.cpp:6140-6156, 6193-6207)
+  for (int kp = wid; kp < base; kp += 4) {
+    const uint32_t k = fb.kp_uvs[kbase + kp];
+    const int x = kp_x(k), y = kp_y(k);
+    int v0 = img[(size_t)(y + lane / 9 - 4) * G.stride + (x + lane % 9 - 4)];
+    int v1 = 0;
+    const int t1 = lane + 64;
+    if (lane < RVO_DESC_LEN - 64) v1 = img[(size_t)(y + t1 / 9 - 4) * G.stride + (x + t1 % 9 - 4)];
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const int mean = wave_sum(v0 + v1) / RVO_DESC_LEN;
+      if (mean < 128) {
+        const int o = 128 - mean;
+        v0 = min(255, v0 + o);
+        if (lane < RVO_DESC_LEN - 64) v1 = min(255, v1 + o);
+      } else if (mean > 128) {
+        const int o = mean - 128;
+        v0 = max(0, v0 - o);
+        if (lane < RVO_DESC_LEN - 64) v1 = max(0, v1 - o);
+      }
+    }
+    uint8_t* dsc = fb.kp_desc + (kbase + kp) * RVO_DESC_LEN;
+    dsc[lane] = (uint8_t)v0;
+    if (lane < RVO_DESC_LEN - 64) dsc[t1] = (uint8_t)v1;
+  }
+}

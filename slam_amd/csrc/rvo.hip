@@ -1,0 +1,436 @@
+// rvo.hip -- host side of librgbdvo_hip.so: context, launch sequencing and the C ABI of include/rvo.h.
+// Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels_frame.h"
+#include "kernels_pair.h"
+#include "rvo_dev.h"
+
+static thread_local std::string g_err;
+struct rvo_ctx;
+static int pair_alloc(rvo_ctx* c);
+const char* rvo_last_error(void) { return g_err.c_str(); }
+
+#define HIPCHK(x)                                                                        \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      g_err = std::string(#x) + ": " + hipGetErrorString(e_);                            \
+      return RVO_E_HIP;                                                                  \
+    }                                                                                    \
+  } while (0)
+
+static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+struct ProfRec { int name; hipEvent_t a, b; };
+
+struct rvo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  rvo_intrinsics intr;
+  rvo_params prm;
+  FrameGeom g;
+  FrameBufs fb;
+  PairBufs pb;
+  CamParams cam;
+  EstParams ep;
+  FastLds fl;
+  int max_frames = 0, max_pairs = 0;
+  std::vector<void*> allocs;
+  std::vector<float> xmap, ymap;
+  int32_t* d_fargs = nullptr;  // [2*max_frames] slots, thr
+  uint8_t* d_gray_stage = nullptr;
+  uint16_t* d_depth_stage = nullptr;
+  size_t stage_frames = 0;
+  // streams
+  StreamState* d_streams = nullptr;
+  rvo_stream_result* d_stream_res = nullptr;
+  int n_streams = 0;
+  int32_t* d_sslots = nullptr;  // [n][4]: curr, ref, prev, thr  (device-written)
+  // profiling
+  bool prof = false;
+  std::vector<std::string> prof_names;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> ev_pool;
+  std::map<int, std::pair<float, int>> prof_acc;
+};
+
+template <class T>
+static int dalloc(rvo_ctx* c, T** p, size_t n) {
+  void* v = nullptr;
+  hipError_t e = hipMalloc(&v, std::max<size_t>(n, 1) * sizeof(T));
+  if (e != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e); return RVO_E_NOMEM; }
+  c->allocs.push_back(v);
+  *p = (T*)v;
+  return 0;
+}
+
+static int prof_id(rvo_ctx* c, const char* name) {
+  for (size_t i = 0; i < c->prof_names.size(); i++) if (c->prof_names[i] == name) return (int)i;
+  c->prof_names.push_back(name);
+  return (int)c->prof_names.size() - 1;
+}
+static hipEvent_t get_event(rvo_ctx* c) {
+  if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+static void prof_drain(rvo_ctx* c) {
+  for (auto& r : c->prof_recs) {
+    (void)hipEventSynchronize(r.b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    auto& acc = c->prof_acc[r.name];
+    acc.first += ms;
+    acc.second += 1;
+    c->ev_pool.push_back(r.a);
+    c->ev_pool.push_back(r.b);
+  }
+  c->prof_recs.clear();
+}
+
+#define LAUNCH(c, NAME, KERNEL, GRID, BLOCK, SHMEM, ...)                                  \
+  do {                                                                                    \
+    ProfRec pr_;                                                                          \
+    if ((c)->prof) {                                                                      \
+      pr_.name = prof_id((c), NAME);                                                      \
+      pr_.a = get_event(c);                                                               \
+      pr_.b = get_event(c);                                                               \
+      (void)hipEventRecord(pr_.a, (c)->stream);                                           \
+    }                                                                                     \
+    hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, (c)->stream, __VA_ARGS__);             \
+    if ((c)->prof) {                                                                      \
+      (void)hipEventRecord(pr_.b, (c)->stream);                                           \
+      (c)->prof_recs.push_back(pr_);                                                      \
+    }                                                                                     \
+  } while (0)
+
+// ---------------------------------------------------------------- defaults (settings.hpp:11-52)
+void rvo_default_vo_params(rvo_params* p) {
+  *p = rvo_params{9, 3, 20, 5, 70, 0.005, 250, 80, 80, 25, 1.5, 0.1, 10, 10.0, 25.0, 250, 100};
+}
+void rvo_default_fm_params(rvo_params* p) {
+  rvo_default_vo_params(p);
+  p->reference_frame_change_threshold = 150;
+}
+
+// Camera::MakeXYMap, camera.cpp:16-67 (host, once per context)
+static void make_xy_map(const rvo_intrinsics& in, std::vector<float>& X, std::vector<float>& Y) {
+  const int W = in.width, H = in.height;
+  X.resize((size_t)W * H);
+  Y.resize((size_t)W * H);
+  const double fx = in.fx, fy = in.fy, cx = in.cx, cy = in.cy, fxp = in.fx, fyp = in.fy, cxp = in.cx, cyp = in.cy;
+  const double k1 = in.k1, k2 = in.k2, k3 = in.k3, p1 = in.p1, p2 = in.p2;
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      double x1 = (x - cx) / fx, y1 = (y - cy) / fy;
+      const double x0 = x1, y0 = y1;
+      for (int j = 0; j < 5; ++j) {
+        const double r2 = x1 * x1 + y1 * y1;
+        const double icdist = 1. / (1. + ((k3 * r2 + k2) * r2 + k1) * r2);
+        const double deltaX = 2 * p1 * x1 * y1 + p2 * (r2 + 2 * x1 * x1);
+        const double deltaY = p1 * (r2 + 2 * y1 * y1) + 2 * p2 * x1 * y1;
+        x1 = (x0 - deltaX) * icdist;
+        y1 = (y0 - deltaY) * icdist;
+      }
+      x1 = x1 * fxp + cxp;
+      y1 = y1 * fyp + cyp;
+      X[(size_t)y * W + x] = (float)x1;
+      Y[(size_t)y * W + x] = (float)y1;
+    }
+}
+
+int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, int max_frames, int max_pairs, rvo_ctx** out) {
+  if (!intr || !prm || !out || max_frames < 1 || max_pairs < 0) { g_err = "rvo_create: bad argument"; return RVO_E_INVALID; }
+  if (prm->feature_window_size != RVO_WIN) { g_err = "feature-window-size must be 9 in this build"; return RVO_E_UNSUPPORTED; }
+  if (prm->num_pyramid_levels < 1 || prm->num_pyramid_levels > RVO_MAX_LEVELS) { g_err = "num-pyramid-levels out of range"; return RVO_E_UNSUPPORTED; }
+  if (prm->grid_width < 8 || prm->grid_height < 8 || prm->max_keypoints_per_grid < 1) { g_err = "grid options out of range"; return RVO_E_UNSUPPORTED; }
+  if (intr->width > 2047 || intr->height > 2047 || intr->width < 32 || intr->height < 32) { g_err = "image size out of range"; return RVO_E_UNSUPPORTED; }
+  if ((intr->width >> (prm->num_pyramid_levels - 1)) < 24 || (intr->height >> (prm->num_pyramid_levels - 1)) < 24) {
+    g_err = "coarsest pyramid level smaller than 24 px"; return RVO_E_UNSUPPORTED;
+  }
+  HIPCHK(hipSetDevice(device));
+  rvo_ctx* c = new rvo_ctx();
+  c->device = device;
+  c->intr = *intr;
+  c->prm = *prm;
+  c->max_frames = max_frames;
+  c->max_pairs = max_pairs;
+  FrameGeom& g = c->g;
+  memset(&g, 0, sizeof(g));
+  g.W = intr->width; g.H = intr->height; g.Wd = intr->depth_width; g.Hd = intr->depth_height;
+  g.levels = prm->num_pyramid_levels;
+  g.gw = prm->grid_width; g.gh = prm->grid_height; g.max_per = prm->max_keypoints_per_grid;
+  g.xs = (float)g.Wd / (float)g.W;
+  g.ys = (float)g.Hd / (float)g.H;
+  g.fx_inv = 1.0 / intr->fx;
+  g.fy_inv = 1.0 / intr->fy;
+  g.neg_cx_div_fx = -intr->cx * g.fx_inv;
+  g.neg_cy_div_fy = -intr->cy * g.fy_inv;
+  int img_off = 0, boff = 0, koff = 0;
+  for (int l = 0; l < g.levels; l++) {
+    LevelGeom& L = g.lv[l];
+    L.w = g.W >> l; L.h = g.H >> l;
+    L.stride = round_up(L.w, 16);
+    L.img_off = img_off;
+    img_off += round_up(L.stride * L.h, 256);
+    L.grows = (int)std::ceil((float)L.h / g.gh);
+    L.gcols = (int)std::ceil((float)L.w / g.gw);
+    L.nbuckets = L.grows * L.gcols;
+    L.bucket_off = boff; boff += L.nbuckets;
+    L.kp_cap = L.nbuckets * g.max_per;
+    L.kp_off = koff; koff += L.kp_cap;
+  }
+  g.img_bytes = img_off; g.total_buckets = boff; g.kp_total = koff;
+  if (koff > 65535) { g_err = "more than 65535 keypoint slots per frame"; delete c; return RVO_E_UNSUPPORTED; }
+  c->cam = CamParams{intr->fx, intr->fy, intr->cx, intr->cy, intr->fx};
+  c->ep = EstParams{prm->inlier_max_reprojection_error, prm->clique_inlier_threshold, prm->max_mean_reprojection_error,
+                    prm->feature_search_window, prm->min_features_for_estimate};
+  // FAST workgroup LDS carve-up
+  FastLds& fl = c->fl;
+  fl.tile_pitch = round_up(g.gw + 8, 4);
+  fl.score_pitch = round_up(g.gw + 2, 4);
+  fl.off_score = round_up(fl.tile_pitch * (g.gh + 8), 16);
+  fl.off_list = fl.off_score + round_up(fl.score_pitch * (g.gh + 2), 16);
+  fl.list_cap = ((g.gw + 1) / 2) * ((g.gh + 1) / 2) + 1;
+  fl.off_misc = fl.off_list + round_up(fl.list_cap * 4, 16);
+  fl.total = fl.off_misc + 64;
+  if (fl.total > 150 * 1024) { g_err = "grid cell too large for LDS"; delete c; return RVO_E_UNSUPPORTED; }
+
+  int rc = 0;
+  HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  FrameBufs& fb = c->fb;
+  const size_t F = max_frames;
+  rc |= dalloc(c, &fb.img, F * g.img_bytes);
+  rc |= dalloc(c, &fb.depth, F * g.Wd * g.Hd);
+  rc |= dalloc(c, &fb.bk_cnt, F * g.total_buckets);
+  rc |= dalloc(c, &fb.bk_det, F * g.total_buckets);
+  rc |= dalloc(c, &fb.bk_kp, F * g.total_buckets * g.max_per);
+  rc |= dalloc(c, &fb.kp_uvs, F * g.kp_total);
+  rc |= dalloc(c, &fb.kp_rect, F * g.kp_total);
+  rc |= dalloc(c, &fb.kp_xyz, F * g.kp_total * 3);
+  rc |= dalloc(c, &fb.kp_desc, F * g.kp_total * RVO_DESC_LEN + 64);
+  rc |= dalloc(c, &fb.kp_cnt, F * RVO_MAX_LEVELS);
+  rc |= dalloc(c, &fb.det_cnt, F * RVO_MAX_LEVELS);
+  rc |= dalloc(c, &fb.grid_cnt, F * RVO_MAX_LEVELS);
+  float *dx = nullptr, *dy = nullptr;
+  rc |= dalloc(c, &dx, (size_t)g.W * g.H + g.W + 2);  // +1 row: BilinearLookup reads ra+W+1 (camera.hpp:103-109)
+  rc |= dalloc(c, &dy, (size_t)g.W * g.H + g.W + 2);
+  rc |= dalloc(c, &c->d_fargs, 2 * F);
+  if (rc) { rvo_destroy(c); return RVO_E_NOMEM; }
+  HIPCHK(hipMemset(fb.img, 0, F * g.img_bytes));  // PyramidLevel ctor memset, pyramid.cpp:121
+  HIPCHK(hipMemset(fb.kp_cnt, 0, F * RVO_MAX_LEVELS * 4));
+  HIPCHK(hipMemset(fb.det_cnt, 0, F * RVO_MAX_LEVELS * 4));
+  HIPCHK(hipMemset(fb.grid_cnt, 0, F * RVO_MAX_LEVELS * 4));
+  make_xy_map(*intr, c->xmap, c->ymap);
+  HIPCHK(hipMemset(dx, 0, ((size_t)g.W * g.H + g.W + 2) * 4));
+  HIPCHK(hipMemset(dy, 0, ((size_t)g.W * g.H + g.W + 2) * 4));
+  HIPCHK(hipMemcpy(dx, c->xmap.data(), c->xmap.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dy, c->ymap.data(), c->ymap.size() * 4, hipMemcpyHostToDevice));
+  fb.xmap = dx; fb.ymap = dy;
+
+  rc = pair_alloc(c);
+  if (rc) { rvo_destroy(c); return rc; }
+  HIPCHK(hipDeviceSynchronize());
+  *out = c;
+  return RVO_OK;
+}
+
+void rvo_destroy(rvo_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  prof_drain(c);
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->d_gray_stage) (void)hipFree(c->d_gray_stage);
+  if (c->d_depth_stage) (void)hipFree(c->d_depth_stage);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int rvo_set_stream(rvo_ctx* c, void* s) {
+  if (!c) return RVO_E_INVALID;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return RVO_OK;
+}
+
+int rvo_sync(rvo_ctx* c) {
+  if (!c) return RVO_E_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return RVO_OK;
+}
+
+// ---------------------------------------------------------------- PrepareFrame
+// enqueue the frame kernels for n frames whose slots/thresholds are at d_slots/d_thr (device)
+static int enqueue_prepare(rvo_ctx* c, int n, const int32_t* d_slots, const int32_t* d_thr) {
+  const FrameGeom& g = c->g;
+  for (int l = 1; l < g.levels; l++) {
+    const int dw = g.lv[l - 1].w / 2, dh = g.lv[l - 1].h / 2;
+    dim3 grid((dw + PYR_TW - 1) / PYR_TW, (dh + PYR_TH - 1) / PYR_TH, n);
+    LAUNCH(c, "pyr_down", k_pyr_down, grid, dim3(256), 0, c->fb, g, d_slots, l);
+  }
+  LAUNCH(c, "fast_grid", k_fast_grid, dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
+  LAUNCH(c, "build_keypoints", k_build_keypoints, dim3(g.levels, n), dim3(256), 0, c->fb, g, d_slots);
+  HIPCHK(hipGetLastError());
+  return RVO_OK;
+}
+
+int rvo_prepare_frames_dev(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* thr, const int32_t* slots) {
+  if (!c || !gray || !depth || !thr || !slots || n < 0 || n > c->max_frames) { g_err = "rvo_prepare_frames: bad argument"; return RVO_E_INVALID; }
+  if (n == 0) return RVO_OK;
+  for (int i = 0; i < n; i++)
+    if (slots[i] < 0 || slots[i] >= c->max_frames) { g_err = "rvo_prepare_frames: slot out of range"; return RVO_E_INVALID; }
+  HIPCHK(hipSetDevice(c->device));
+  const FrameGeom& g = c->g;
+  std::vector<int32_t> args(2 * (size_t)n);
+  memcpy(args.data(), slots, n * 4);
+  memcpy(args.data() + n, thr, n * 4);
+  HIPCHK(hipMemcpyAsync(c->d_fargs, args.data(), args.size() * 4, hipMemcpyHostToDevice, c->stream));
+  // level-0 copy (frame.cpp:47-50) and raw depth into the slots
+  for (int i = 0; i < n; i++) {
+    uint8_t* dst = c->fb.img + (size_t)slots[i] * g.img_bytes + g.lv[0].img_off;
+    HIPCHK(hipMemcpy2DAsync(dst, g.lv[0].stride, gray + (size_t)i * g.W * g.H, g.W, g.W, g.H, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->fb.depth + (size_t)slots[i] * g.Wd * g.Hd, depth + (size_t)i * g.Wd * g.Hd, (size_t)g.Wd * g.Hd * 2,
+                          hipMemcpyDeviceToDevice, c->stream));
+  }
+  return enqueue_prepare(c, n, c->d_fargs, c->d_fargs + n);
+}
+
+int rvo_prepare_frames(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* thr, const int32_t* slots) {
+  if (!c || !gray || !depth || n < 0 || n > c->max_frames) { g_err = "rvo_prepare_frames: bad argument"; return RVO_E_INVALID; }
+  if (n == 0) return RVO_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const FrameGeom& g = c->g;
+  if (c->stage_frames < (size_t)n) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_gray_stage) (void)hipFree(c->d_gray_stage);
+    if (c->d_depth_stage) (void)hipFree(c->d_depth_stage);
+    c->d_gray_stage = nullptr; c->d_depth_stage = nullptr; c->stage_frames = 0;
+    HIPCHK(hipMalloc((void**)&c->d_gray_stage, (size_t)n * g.W * g.H));
+    HIPCHK(hipMalloc((void**)&c->d_depth_stage, (size_t)n * g.Wd * g.Hd * 2));
+    c->stage_frames = n;
+  }
+  HIPCHK(hipMemcpyAsync(c->d_gray_stage, gray, (size_t)n * g.W * g.H, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_depth_stage, depth, (size_t)n * g.Wd * g.Hd * 2, hipMemcpyHostToDevice, c->stream));
+  int rc = rvo_prepare_frames_dev(c, n, c->d_gray_stage, c->d_depth_stage, thr, slots);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return RVO_OK;
+}
+
+// ---------------------------------------------------------------- dump accessors
+static int check_slot_level(rvo_ctx* c, int slot, int level) {
+  if (!c || slot < 0 || slot >= c->max_frames || level < 0 || level >= c->g.levels) { g_err = "slot/level out of range"; return RVO_E_INVALID; }
+  return 0;
+}
+
+int rvo_get_level_info(rvo_ctx* c, int slot, int level, int32_t* info) {
+  if (check_slot_level(c, slot, level) || !info) return RVO_E_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const LevelGeom& L = c->g.lv[level];
+  int32_t v[3];
+  HIPCHK(hipMemcpy(&v[0], c->fb.kp_cnt + slot * RVO_MAX_LEVELS + level, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&v[1], c->fb.det_cnt + slot * RVO_MAX_LEVELS + level, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&v[2], c->fb.grid_cnt + slot * RVO_MAX_LEVELS + level, 4, hipMemcpyDeviceToHost));
+  info[0] = L.w; info[1] = L.h; info[2] = L.stride; info[3] = v[0]; info[4] = v[1]; info[5] = v[2];
+  return RVO_OK;
+}
+
+int rvo_get_level_image(rvo_ctx* c, int slot, int level, uint8_t* out) {
+  if (check_slot_level(c, slot, level) || !out) return RVO_E_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const LevelGeom& L = c->g.lv[level];
+  HIPCHK(hipMemcpy(out, c->fb.img + (size_t)slot * c->g.img_bytes + L.img_off, (size_t)L.stride * L.h, hipMemcpyDeviceToHost));
+  return RVO_OK;
+}
+
+int rvo_get_grid_keypoints(rvo_ctx* c, int slot, int level, float* uvs) {
+  if (check_slot_level(c, slot, level) || !uvs) return RVO_E_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const FrameGeom& g = c->g;
+  const LevelGeom& L = g.lv[level];
+  std::vector<int32_t> cnt(L.nbuckets);
+  std::vector<uint32_t> kp((size_t)L.nbuckets * g.max_per);
+  HIPCHK(hipMemcpy(cnt.data(), c->fb.bk_cnt + (size_t)slot * g.total_buckets + L.bucket_off, cnt.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(kp.data(), c->fb.bk_kp + ((size_t)slot * g.total_buckets + L.bucket_off) * g.max_per, kp.size() * 4, hipMemcpyDeviceToHost));
+  size_t o = 0;
+  for (int b = 0; b < L.nbuckets; b++)
+    for (int j = 0; j < cnt[b]; j++) {
+      uint32_t k = kp[(size_t)b * g.max_per + j];
+      uvs[o++] = (float)kp_x(k); uvs[o++] = (float)kp_y(k); uvs[o++] = (float)kp_s(k);
+    }
+  return RVO_OK;
+}
+
+int rvo_get_keypoints(rvo_ctx* c, int slot, int level, float* uvs, double* rect, double* xyz) {
+  if (check_slot_level(c, slot, level)) return RVO_E_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const FrameGeom& g = c->g;
+  const LevelGeom& L = g.lv[level];
+  int32_t n = 0;
+  HIPCHK(hipMemcpy(&n, c->fb.kp_cnt + slot * RVO_MAX_LEVELS + level, 4, hipMemcpyDeviceToHost));
+  const size_t base = (size_t)slot * g.kp_total + L.kp_off;
+  std::vector<uint32_t> k(n);
+  std::vector<float2> r(n);
+  HIPCHK(hipMemcpy(k.data(), c->fb.kp_uvs + base, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(r.data(), c->fb.kp_rect + base, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (xyz) HIPCHK(hipMemcpy(xyz, c->fb.kp_xyz + base * 3, (size_t)n * 24, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) {
+    if (uvs) { uvs[3 * i] = (float)kp_x(k[i]); uvs[3 * i + 1] = (float)kp_y(k[i]); uvs[3 * i + 2] = (float)kp_s(k[i]); }
+    if (rect) { rect[2 * i] = r[i].x; rect[2 * i + 1] = r[i].y; }
+  }
+  return RVO_OK;
+}
+
+int rvo_get_descriptors(rvo_ctx* c, int slot, int level, uint8_t* out) {
+  if (check_slot_level(c, slot, level) || !out) return RVO_E_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const FrameGeom& g = c->g;
+  int32_t n = 0;
+  HIPCHK(hipMemcpy(&n, c->fb.kp_cnt + slot * RVO_MAX_LEVELS + level, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, c->fb.kp_desc + ((size_t)slot * g.kp_total + g.lv[level].kp_off) * RVO_DESC_LEN, (size_t)n * RVO_DESC_LEN,
+                   hipMemcpyDeviceToHost));
+  return RVO_OK;
+}
+
+int rvo_get_lut(rvo_ctx* c, float* xmap, float* ymap) {
+  if (!c || !xmap || !ymap) return RVO_E_INVALID;
+  memcpy(xmap, c->xmap.data(), c->xmap.size() * 4);
+  memcpy(ymap, c->ymap.data(), c->ymap.size() * 4);
+  return RVO_OK;
+}
+
+int rvo_profile_enable(rvo_ctx* c, int on) {
+  if (!c) return RVO_E_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  c->prof_acc.clear();
+  c->prof = on != 0;
+  return RVO_OK;
+}
+
+int rvo_profile_read(rvo_ctx* c, int cap, const char** names, float* total_ms, int32_t* calls) {
+  if (!c) return RVO_E_INVALID;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  int n = 0;
+  for (auto& kv : c->prof_acc) {
+    if (n < cap) { names[n] = c->prof_names[kv.first].c_str(); total_ms[n] = kv.second.first; calls[n] = kv.second.second; }
+    n++;
+  }
+  return n;
+}
+
+
+#include "rvo_pair_api.inc"

@@ -1,0 +1,93 @@
+// rvo_dev.h -- device-side layouts shared by the kernels and the host API.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rvo.h"
+
+#define RVO_DESC_LEN 80  // feature.cpp:6081-6091: window 9 -> 81 px -> (81-1)%16==0 -> 80, stride 80, pad 0
+#define RVO_WIN 9
+
+// One pyramid level of a frame slot.
+struct LevelGeom {
+  int w, h, stride;  // stride = round_up(w,16)  (pyramid.cpp:114)
+  int img_off;       // byte offset of the level image inside the slot's image block
+  int gcols, grows;  // GridKeyPointFilter buckets (pyramid.hpp:13-21)
+  int nbuckets;
+  int bucket_off;    // first bucket of this level in the slot's bucket arrays
+  int kp_cap;        // nbuckets * max_keypoints_per_grid
+  int kp_off;        // first keypoint of this level in the slot's keypoint arrays
+};
+
+struct FrameGeom {
+  int W, H, Wd, Hd;
+  int levels;
+  int gw, gh, max_per;
+  int img_bytes;       // per slot
+  int total_buckets;   // per slot
+  int kp_total;        // per slot (sum of kp_cap)
+  float xs, ys;        // Depth::x_scale_/y_scale_ (depth.cpp:14-15)
+  double fx_inv, fy_inv, neg_cx_div_fx, neg_cy_div_fy;  // depth.cpp:23-26
+  LevelGeom lv[RVO_MAX_LEVELS];
+};
+
+// Packed keypoint: x | y<<11 | score<<22  (level dims <= 2047, FAST score <= 254)
+__host__ __device__ inline uint32_t kp_pack(int x, int y, int s) { return (uint32_t)x | ((uint32_t)y << 11) | ((uint32_t)s << 22); }
+__host__ __device__ inline int kp_x(uint32_t k) { return k & 0x7FF; }
+__host__ __device__ inline int kp_y(uint32_t k) { return (k >> 11) & 0x7FF; }
+__host__ __device__ inline int kp_s(uint32_t k) { return k >> 22; }
+
+// All frame slots, structure-of-arrays; index = slot * per_slot_extent + ...
+struct FrameBufs {
+  uint8_t* img;       // [slots][img_bytes]
+  uint16_t* depth;    // [slots][Wd*Hd] raw millimetres, 0 = invalid (vo.cpp:83-87 conversion is done lazily)
+  int32_t* bk_cnt;    // [slots][total_buckets] kept per bucket (<= max_per)
+  int32_t* bk_det;    // [slots][total_buckets] NMS survivors per bucket
+  uint32_t* bk_kp;    // [slots][total_buckets][max_per] packed, post-nth_element order
+  uint32_t* kp_uvs;   // [slots][kp_total] packed keypoints after the border/LUT/depth filter
+  float2* kp_rect;    // [slots][kp_total] rect_base_uv (LUT values are floats, exact)
+  double* kp_xyz;     // [slots][kp_total][3]
+  uint8_t* kp_desc;   // [slots][kp_total][80]
+  int32_t* kp_cnt;    // [slots][RVO_MAX_LEVELS]
+  int32_t* det_cnt;   // [slots][RVO_MAX_LEVELS] FAST corners after NMS (adaptive threshold input)
+  int32_t* grid_cnt;  // [slots][RVO_MAX_LEVELS] candidates after the grid filter
+  const float* xmap;  // [H][W] Camera::Xmap_ (camera.cpp:63)
+  const float* ymap;
+};
+
+// match record of a pair (FeatureMatch, feature.hpp:210-308), structure-of-arrays per pair
+struct PairBufs {
+  int32_t* ref_slot;   // [pairs]
+  int32_t* tgt_slot;   // [pairs]
+  int32_t* active;     // [pairs] 0 = skip every stage for this pair
+  double* init_pose;   // [pairs][12]
+  double* q0;          // [pairs][4]
+  int32_t* lm_cnt;     // [pairs][RVO_MAX_LEVELS] matches per level
+  int32_t* lm_ref;     // [pairs][kp_total] level segments at lv.kp_off
+  int32_t* lm_tgt;
+  int32_t* n_matches;  // [pairs]
+  int32_t* m_ref;      // [pairs][mcap] level-local keypoint index
+  int32_t* m_tgt;
+  uint8_t* m_level;    // [pairs][mcap]
+  uint8_t* m_status;
+  float2* m_uv;        // refined kp.u, kp.v
+  double* m_rect;      // [pairs][mcap][2] refined rect_base_uv
+  double* m_xyz;       // [pairs][mcap][3] refined xyz
+  int32_t* m_degree;   // [pairs][mcap]
+  uint8_t* m_inlier;   // [pairs][mcap] indexed by id
+  double* m_reproj;    // [pairs][mcap] indexed by id
+  uint32_t* order;     // [pairs][mcap] sorted keys degree<<16|id
+  uint32_t* cbits;     // [pairs][mcap][cwords] consistency bit matrix
+  rvo_pair_result* result;  // [pairs]
+  int mcap, cwords;
+};
+
+struct CamParams {
+  double fx, fy, cx, cy;  // rectified camera (camera.cpp:7-12)
+  double in_fx;           // input camera fx (motion_estimate.cpp:297-299)
+};
+
+struct EstParams {
+  double inlier_max_reprojection_error, clique_inlier_threshold, max_mean_reprojection_error, feature_search_window;
+  int min_features;
+};
