@@ -287,6 +287,9 @@ struct Depth {  // depth.cpp / depth.hpp
     float v_f_d = v_f * y_scale, u_f_d = u_f * x_scale;
     int32_t v = (int32_t)v_f_d, u = (int32_t)u_f_d;
     float wright = (u_f_d - u), wbottom = (v_f_d - v);
+    // depth.cpp:109 asserts these bounds (the reference aborts outside them); a batch API cannot
+    // abort, so an out-of-range refined position is reported as a failed refinement instead.
+    if (!(u >= 0 && v >= 0 && u < dw - 1 && v < dh - 1)) return false;
     float w[4] = {(1 - wright) * (1 - wbottom), wright * (1 - wbottom), (1 - wright) * wbottom,
                   wright * wbottom};
     int32_t di = v * dw + u;
@@ -1111,6 +1114,11 @@ struct MotionEstimator {
   void EstimateMotion(Frame* r, Frame* t, const Iso& init) {
     ref = r; tgt = t;
     motion = init;
+    // *_motion_estimate_covariance = init_motion_cov: both callers pass an empty (0x0) MatrixXd
+    // (vo.cpp:115, fm.cpp:42-43); reported here as all zeros.  _mean_reprojection_error is never
+    // initialised by the reference ctor and goes stale across calls: reset to 0.
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) cov[i][j] = 0;
+    mean_reprojection_error = 0;
     matches.clear();
     for (int l = 0; l < ref->num_levels; l++) matchFeatures(l);
     // Depth::RefineXYZ, depth.cpp:80-95 (depth source = the target frame's depth image)

@@ -39,6 +39,35 @@ __device__ inline int block_excl_scan_256(int v, int* s_wave, int* total) {
   return base + inc - v;
 }
 
+// ------------------------------------------------------------------ ingest
+// Level-0 copy (frame.cpp:47-50) and raw depth copy into the frame slots; grid (blocks, n_frames).
+// VEC: 16-byte path (W % 16 == 0, Wd*Hd % 8 == 0 and 16-byte aligned sources).
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_ingest(FrameBufs fb, FrameGeom g, const uint8_t* __restrict__ gray,
+                                                const uint16_t* __restrict__ depth, const int32_t* __restrict__ slots) {
+  const int f = blockIdx.y;
+  const int slot = slots[f];
+  if (slot < 0) return;
+  const size_t npx = (size_t)g.W * g.H, ndp = (size_t)g.Wd * g.Hd;
+  const uint8_t* gs = gray + f * npx;
+  const uint16_t* dsrc = depth + f * ndp;
+  uint8_t* gd = fb.img + (size_t)slot * g.img_bytes + g.lv[0].img_off;
+  uint16_t* dd = fb.depth + (size_t)slot * ndp;
+  const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+  if (VEC) {
+    const int cpr = g.W / 16, spr = g.lv[0].stride / 16;
+    const uint4* s4 = reinterpret_cast<const uint4*>(gs);
+    uint4* d4 = reinterpret_cast<uint4*>(gd);
+    for (int i = tid; i < cpr * g.H; i += nth) d4[(i / cpr) * spr + i % cpr] = s4[i];
+    const uint4* ds4 = reinterpret_cast<const uint4*>(dsrc);
+    uint4* dd4 = reinterpret_cast<uint4*>(dd);
+    for (int i = tid; i < (int)(ndp / 8); i += nth) dd4[i] = ds4[i];
+  } else {
+    for (int i = tid; i < (int)npx; i += nth) gd[(size_t)(i / g.W) * g.lv[0].stride + i % g.W] = gs[i];
+    for (int i = tid; i < (int)ndp; i += nth) dd[i] = dsrc[i];
+  }
+}
+
 // ------------------------------------------------------------------ pyramid
 #define PYR_TW 64
 #define PYR_TH 16
@@ -60,6 +89,7 @@ __device__ inline int gauss_tap(F at, int n, int r) {
 __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots, int lvl) {
   const LevelGeom S = g.lv[lvl - 1], D = g.lv[lvl];
   const int slot = slots[blockIdx.z];
+  if (slot < 0) return;  // stream still in warm-up (vo.cpp:58-69)
   const uint8_t* __restrict__ src = fb.img + (size_t)slot * g.img_bytes + S.img_off;
   uint8_t* __restrict__ dst = fb.img + (size_t)slot * g.img_bytes + D.img_off;
   const int dw = S.w / 2, dh = S.h / 2;
@@ -175,6 +205,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
 
   const int tid = threadIdx.x;
   const int slot = slots[blockIdx.y];
+  if (slot < 0) return;
   const int b = thr[blockIdx.y];
   int lvl = 0;
   const int gb = blockIdx.x;  // bucket index within the slot
@@ -271,6 +302,7 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lvl = blockIdx.x;
   const int slot = slots[blockIdx.y];
+  if (slot < 0) return;
   const LevelGeom G = g.lv[lvl];
   const uint8_t* __restrict__ img = fb.img + (size_t)slot * g.img_bytes + G.img_off;
   const uint16_t* __restrict__ depth = fb.depth + (size_t)slot * g.Wd * g.Hd;

@@ -1,3 +1,1135 @@
+// kernels_pair.h -- MotionEstimator on the GPU (rgbdvo/motion_estimate.cpp), one frame pair per workgroup
+// (or per wave) with thousands of pairs in flight:
+//   k_init_rotation  EstimateInitialRotation + InitialHomographyEstimator   :268-304, 1333-1571
+//   k_match          candidate windows + SAD mutual matching                 :307-345, feature.cpp:6239-6335
+//   k_refine         sub-pixel ESM, rectified lookup, depth refinement       :347-378, 757-900, depth.cpp:80-162
+//   k_consistency    pairwise rigid-distance consistency bit matrix          :470-523
+//   k_clique         degree sort (libstdc++ std::sort replay) + greedy clique :526-569
+//   k_gn             bidirectional Gauss-Newton, reprojection pruning, status :198-232, 610-720, 1208-1331
+// fp64 expressions keep the evaluation order of oracle/rvo_oracle.cpp (no FMA contraction); reductions over
+// matches are tree-ordered here and sequential there, which is the only source of (1e-16-level) differences.
 #pragma once
+#include "kernels_frame.h"
 #include "rvo_dev.h"
-struct StreamState { int dummy; };
+#include "stdalgo.h"
+
+#define NONE_KEY 0xFFFFFFFFu
+
+// ------------------------------------------------------------------ small fp64 geometry
+struct DIso { double R[9]; double t[3]; };
+struct DQuat { double w, x, y, z; };
+
+__device__ inline void iso_identity(DIso& m) {
+  for (int i = 0; i < 9; i++) m.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  m.t[0] = m.t[1] = m.t[2] = 0.0;
+}
+__device__ inline void iso_load(DIso& m, const double* p) {
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) m.R[i * 3 + j] = p[i * 4 + j]; m.t[i] = p[i * 4 + 3]; }
+}
+__device__ inline void iso_store(const DIso& m, double* p) {
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) p[i * 4 + j] = m.R[i * 3 + j]; p[i * 4 + 3] = m.t[i]; }
+}
+__device__ inline DIso iso_inverse(const DIso& a) {
+  DIso r;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.R[i * 3 + j] = a.R[j * 3 + i];
+  for (int i = 0; i < 3; i++) r.t[i] = -((r.R[i * 3] * a.t[0] + r.R[i * 3 + 1] * a.t[1]) + r.R[i * 3 + 2] * a.t[2]);
+  return r;
+}
+__device__ inline DIso iso_mul(const DIso& a, const DIso& b) {
+  DIso r;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) r.R[i * 3 + j] = (a.R[i * 3] * b.R[j] + a.R[i * 3 + 1] * b.R[3 + j]) + a.R[i * 3 + 2] * b.R[6 + j];
+    r.t[i] = ((a.R[i * 3] * b.t[0] + a.R[i * 3 + 1] * b.t[1]) + a.R[i * 3 + 2] * b.t[2]) + a.t[i];
+  }
+  return r;
+}
+__device__ inline void quat_to_R(const DQuat& q, double* R) {
+  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+__device__ inline DQuat R_to_quat(const double* m) {
+  DQuat q;
+  double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q.w = 0.5 * t;
+    t = 0.5 / t;
+    q.x = (m[7] - m[5]) * t;
+    q.y = (m[2] - m[6]) * t;
+    q.z = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[i * 4] - m[j * 4] - m[k * 4] + 1.0);
+    double v[3];
+    v[i] = 0.5 * t;
+    t = 0.5 / t;
+    q.w = (m[k * 3 + j] - m[j * 3 + k]) * t;
+    v[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+    v[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    q.x = v[0]; q.y = v[1]; q.z = v[2];
+  }
+  return q;
+}
+__device__ inline void iso_rotate(DIso& a, const DQuat& q) {
+  double Rq[9], L[9];
+  quat_to_R(q, Rq);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) L[i * 3 + j] = (a.R[i * 3] * Rq[j] + a.R[i * 3 + 1] * Rq[3 + j]) + a.R[i * 3 + 2] * Rq[6 + j];
+  for (int i = 0; i < 9; i++) a.R[i] = L[i];
+}
+__device__ inline DQuat rpy_to_quat(double roll, double pitch, double yaw) {
+  const double hr = roll / 2, hp = pitch / 2, hy = yaw / 2;
+  const double sr = sin(hr), sp = sin(hp), sy = sin(hy), cr = cos(hr), cp = cos(hp), cy = cos(hy);
+  DQuat q;
+  q.w = cr * cp * cy + sr * sp * sy;
+  q.x = sr * cp * cy - cr * sp * sy;
+  q.y = cr * sp * cy + sr * cp * sy;
+  q.z = cr * cp * sy - sr * sp * cy;
+  return q;
+}
+__device__ inline DIso iso_from_params(const double* p) {
+  DIso r;
+  iso_identity(r);
+  r.t[0] = p[0]; r.t[1] = p[1]; r.t[2] = p[2];
+  iso_rotate(r, rpy_to_quat(p[3], p[4], p[5]));
+  return r;
+}
+__device__ inline void iso_to_params(const DIso& M, double* p) {
+  const DQuat q = R_to_quat(M.R);
+  const double roll_a = 2 * (q.w * q.x + q.y * q.z), roll_b = 1 - 2 * (q.x * q.x + q.y * q.y);
+  const double pitch_sin = 2 * (q.w * q.y - q.z * q.x);
+  const double yaw_a = 2 * (q.w * q.z + q.x * q.y), yaw_b = 1 - 2 * (q.y * q.y + q.z * q.z);
+  p[0] = M.t[0]; p[1] = M.t[1]; p[2] = M.t[2];
+  p[3] = atan2(roll_a, roll_b);
+  p[4] = asin(pitch_sin);
+  p[5] = atan2(yaw_a, yaw_b);
+}
+// K * motion.matrix(), K = [fx 0 px 0; 0 fy py 0; 0 0 1 0]; zeros kept so the rounding matches the host restatement
+__device__ inline void proj_matrix(double fx, double fy, double px, double py, const DIso& m, double* P /*[12]*/) {
+  const double K[12] = {fx, 0, px, 0, 0, fy, py, 0, 0, 0, 1, 0};
+  const double M[16] = {m.R[0], m.R[1], m.R[2], m.t[0], m.R[3], m.R[4], m.R[5], m.t[1], m.R[6], m.R[7], m.R[8], m.t[2], 0, 0, 0, 1};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++)
+      P[i * 4 + j] = ((K[i * 4] * M[j] + K[i * 4 + 1] * M[4 + j]) + K[i * 4 + 2] * M[8 + j]) + K[i * 4 + 3] * M[12 + j];
+}
+__device__ inline double dot4(const double* r, double x, double y, double z, double w) {
+  return ((r[0] * x + r[1] * y) + r[2] * z) + r[3] * w;
+}
+
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline uint32_t wave_min_u(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+  return v;
+}
+
+// sum N doubles per thread over a 256-thread block; result valid in every thread. s_red: N*4 doubles.
+template <int N>
+__device__ inline void block_sum_d(double* v, double* s_red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const double s = wave_sum_d(v[i]);
+    if (lane == 0) s_red[i * 4 + wid] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = ((s_red[i * 4] + s_red[i * 4 + 1]) + s_red[i * 4 + 2]) + s_red[i * 4 + 3];
+}
+
+// ------------------------------------------------------------------ initial rotation
+// grid (n_pairs), 256 threads, dynamic LDS = 5 * npx floats + 64 doubles.
+// mode 0: write q0 only; mode 1: also init_pose = Identity.rotate(q0) (fm.cpp:41-47).
+__global__ __launch_bounds__(256) void k_init_rotation(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, int mode) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  if (!pb.active[pair]) return;
+  const int irl = 4;
+  const int pyr = min(g.levels - 1, irl);
+  const int ds = irl - pyr;
+  const LevelGeom G = g.lv[pyr];
+  const int cols = G.w >> ds, rows = G.h >> ds, npx = cols * rows;
+  float* tmpl = reinterpret_cast<float*>(lds);
+  float* test = tmpl + npx;
+  float* tdx = test + npx;
+  float* tdy = tdx + npx;
+  float* warped = tdy + npx;
+  double* s_red = reinterpret_cast<double*>(lds + (((size_t)5 * npx * 4 + 15) & ~(size_t)15));
+
+  const uint8_t* rimg = fb.img + (size_t)pb.rot_slot[pair] * g.img_bytes + G.img_off;
+  const uint8_t* timg = fb.img + (size_t)pb.tgt_slot[pair] * g.img_bytes + G.img_off;
+  // grayToEigen, motion_estimate.cpp:1338-1367 (box sums are exact in float)
+  const int f = 1 << ds;
+  const double pf2 = (double)f * (double)f;
+  for (int i = tid; i < npx; i += 256) {
+    const int ey = i / cols, ex = i % cols;
+    float a = 0.f, b = 0.f;
+    for (int y = 0; y < f; y++)
+      for (int x = 0; x < f; x++) {
+        a += (float)rimg[(size_t)(ey * f + y) * G.stride + ex * f + x];
+        b += (float)timg[(size_t)(ey * f + y) * G.stride + ex * f + x];
+      }
+    tmpl[i] = ds > 0 ? (float)((double)a / pf2) : a;
+    test[i] = ds > 0 ? (float)((double)b / pf2) : b;
+  }
+  __syncthreads();
+  auto grad = [&](const float* im, int x, int y, float& vx, float& vy) {  // computeGradient, :1494-1517
+    if (x == 0) vx = im[y * cols + 1] - im[y * cols];
+    else if (x == cols - 1) vx = im[y * cols + x] - im[y * cols + x - 1];
+    else vx = (float)((double)(im[y * cols + x + 1] - im[y * cols + x - 1]) / 2.0);
+    if (y == 0) vy = im[cols + x] - im[x];
+    else if (y == rows - 1) vy = im[y * cols + x] - im[(y - 1) * cols + x];
+    else vy = (float)((double)(im[(y + 1) * cols + x] - im[(y - 1) * cols + x]) / 2.0);
+  };
+  for (int i = tid; i < npx; i += 256) grad(tmpl, i % cols, i / cols, tdx[i], tdy[i]);
+
+  float H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, bestH[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double minError = INFINITY, lastRMS = INFINITY;
+  int bestIter = 0, lastImproved = 0;
+  for (int iter = 0; iter < 8; iter++) {
+    __syncthreads();
+    // constructWarpedImage, :1538-1571
+    for (int i = tid; i < npx; i += 256) {
+      const int y = i / cols, x = i % cols;
+      const float hx = (H[0] * (float)x + H[1] * (float)y) + H[2] * 1.f;
+      const float hy = (H[3] * (float)x + H[4] * (float)y) + H[5] * 1.f;
+      const float hw = (H[6] * (float)x + H[7] * (float)y) + H[8] * 1.f;
+      const float px = hx / hw, py = hy / hw;
+      const int fx0 = (int)floorf(px), fy0 = (int)floorf(py), cx0 = (int)ceilf(px), cy0 = (int)ceilf(py);
+      double val;
+      if (0 <= px && px < (float)(cols - 1) && 0 <= py && py < (float)(rows - 1)) {
+        const double x1 = (double)(px - (float)fx0), y1 = (double)(py - (float)fy0), x2 = 1 - x1, y2 = 1 - y1;
+        val = ((x2 * y2 * (double)test[fy0 * cols + fx0] + x1 * y2 * (double)test[fy0 * cols + fx0 + 1]) +
+               x2 * y1 * (double)test[(fy0 + 1) * cols + fx0]) + x1 * y1 * (double)test[(fy0 + 1) * cols + fx0 + 1];
+      } else if (0 <= fx0 && fx0 < cols && 0 <= fy0 && fy0 < rows) {
+        val = test[fy0 * cols + fx0];
+      } else if (0 <= cx0 && cx0 < cols && 0 <= cy0 && cy0 < rows) {
+        val = test[cy0 * cols + cx0];
+      } else {
+        val = 128;
+      }
+      warped[i] = (float)val;
+    }
+    __syncthreads();
+    // error, gradients of the warped image, normal equations J'J, J'e
+    double acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) acc[k] = 0;
+    for (int i = tid; i < npx; i += 256) {
+      const int y = i / cols, x = i % cols;
+      const float e = warped[i] - tmpl[i];
+      float wx, wy;
+      grad(warped, x, y, wx, wy);
+      const float jx = tdx[i] + wx, jy = tdy[i] + wy;
+      const float j2 = jx * (float)(y + 1) - jy * (float)(x + 1);
+      const double J0 = jx, J1 = jy, J2 = j2, E = e;
+      acc[0] += J0 * J0; acc[1] += J0 * J1; acc[2] += J0 * J2; acc[3] += J1 * J1; acc[4] += J1 * J2; acc[5] += J2 * J2;
+      acc[6] += J0 * E; acc[7] += J1 * E; acc[8] += J2 * E;
+      acc[9] += E * E;
+    }
+    block_sum_d<10>(acc, s_red);
+    // everything below is computed identically by every thread
+    const double rms = sqrt(acc[9]) / sqrt((double)npx);
+    if (rms < minError) { minError = rms; for (int k = 0; k < 9; k++) bestH[k] = H[k]; bestIter = iter; }
+    const double A00 = acc[0], A01 = acc[1], A02 = acc[2], A11 = acc[3], A12 = acc[4], A22 = acc[5];
+    const double A10 = A01, A20 = A02, A21 = A12;
+    double lie[3] = {0, 0, 0};
+    const double det = A00 * (A11 * A22 - A12 * A21) - A01 * (A10 * A22 - A12 * A20) + A02 * (A10 * A21 - A11 * A20);
+    const double scale = A00 * A11 * A22;
+    if (fabs(det) > 1e-12 * fabs(scale) && isfinite(det) && det != 0) {
+      double inv[9];
+      inv[0] = (A11 * A22 - A12 * A21) / det; inv[1] = (A02 * A21 - A01 * A22) / det; inv[2] = (A01 * A12 - A02 * A11) / det;
+      inv[3] = (A12 * A20 - A10 * A22) / det; inv[4] = (A00 * A22 - A02 * A20) / det; inv[5] = (A02 * A10 - A00 * A12) / det;
+      inv[6] = (A10 * A21 - A11 * A20) / det; inv[7] = (A01 * A20 - A00 * A21) / det; inv[8] = (A00 * A11 - A01 * A10) / det;
+      for (int a = 0; a < 3; a++) lie[a] = (double)(float)(-2 * ((inv[a * 3] * acc[6] + inv[a * 3 + 1] * acc[7]) + inv[a * 3 + 2] * acc[8]));
+    }
+    const double a = lie[2];
+    double sa, ca1;
+    if (fabs(a) < 1e-8) { sa = 1 - a * a / 6; ca1 = a / 2; } else { sa = sin(a) / a; ca1 = (1 - cos(a)) / a; }
+    const float E[9] = {(float)cos(a), (float)sin(a), (float)(sa * lie[0] + ca1 * lie[1]),
+                        (float)-sin(a), (float)cos(a), (float)(-ca1 * lie[0] + sa * lie[1]), 0.f, 0.f, 1.f};
+    float Hn[9];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) Hn[r * 3 + c] = (H[r * 3] * E[c] + H[r * 3 + 1] * E[3 + c]) + H[r * 3 + 2] * E[6 + c];
+    for (int k = 0; k < 9; k++) H[k] = Hn[k];
+    if (rms < lastRMS) lastImproved = iter;
+    const float l0 = (float)lie[0], l1 = (float)lie[1], l2 = (float)lie[2];
+    const double lnorm = sqrt((double)(l0 * l0 + l1 * l1 + l2 * l2));
+    if (lnorm < 1e-6 || (rms - minError > 3 && iter - bestIter > 2) || iter - bestIter > 4 || iter - lastImproved > 2) break;
+    lastRMS = rms;
+  }
+  if (tid == 0) {
+    const double sf = (double)(1 << irl);
+    const double h12 = (double)(float)(bestH[5] * (float)sf), h02 = (double)(float)(bestH[2] * (float)sf);
+    const double roll = asin(h12 / cam.in_fx), pitch = -asin(h02 / cam.in_fx), yaw = -atan2((double)bestH[3], (double)bestH[0]);
+    const DQuat q = rpy_to_quat(roll, pitch, yaw);
+    double* qo = pb.q0 + pair * 4;
+    qo[0] = q.w; qo[1] = q.x; qo[2] = q.y; qo[3] = q.z;
+    if (mode == 1) {
+      DIso init;
+      iso_identity(init);
+      iso_rotate(init, q);
+      iso_store(init, pb.init_pose + pair * 12);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ matching
+// grid (levels, n_pairs), 256 threads; dynamic LDS = kp_cap(level 0) * 16 bytes + 16.
+__global__ __launch_bounds__(256) void k_match(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, EstParams ep) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const int lvl = blockIdx.x, pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (!pb.active[pair]) return;
+  const LevelGeom G = g.lv[lvl];
+  const int cap = g.lv[0].kp_cap;
+  float2* s_tuv = reinterpret_cast<float2*>(lds);
+  uint32_t* s_bt = reinterpret_cast<uint32_t*>(lds + (size_t)cap * 8);
+  uint32_t* s_br = s_bt + cap;
+  int* s_wave = reinterpret_cast<int*>(s_br + cap);
+  const int rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
+  const int nr = fb.kp_cnt[rs * RVO_MAX_LEVELS + lvl], nt = fb.kp_cnt[ts * RVO_MAX_LEVELS + lvl];
+  const size_t rbase = (size_t)rs * g.kp_total + G.kp_off, tbase = (size_t)ts * g.kp_total + G.kp_off;
+
+  // reproj_mat = K_rect * (motion_estimate^-1), motion_estimate.cpp:309-313
+  DIso init;
+  iso_load(init, pb.init_pose + pair * 12);
+  const DIso r2t = iso_inverse(init);
+  double RP[12];
+  proj_matrix(cam.fx, cam.fy, cam.cx, cam.cy, r2t, RP);
+
+  for (int i = tid; i < nt; i += 256) { s_tuv[i] = fb.kp_rect[tbase + i]; s_bt[i] = NONE_KEY; }
+  for (int i = tid; i < nr; i += 256) s_br[i] = NONE_KEY;
+  __syncthreads();
+
+  const double win = ep.feature_search_window;
+  const double win2 = win * win, lo2 = win2 * (1.0 - 1e-9), hi2 = win2 * (1.0 + 1e-9);
+  for (int r0 = wid; r0 < nr; r0 += 4) {
+    const int r = __builtin_amdgcn_readfirstlane(r0);
+    const double* X = fb.kp_xyz + (rbase + r) * 3;
+    const double u = dot4(RP, X[0], X[1], X[2], 1.0), v = dot4(RP + 4, X[0], X[1], X[2], 1.0), w = dot4(RP + 8, X[0], X[1], X[2], 1.0);
+    const double inv = 1.0 / w;  // Eigen 3.2 `v /= s` multiplies by the reciprocal
+    const double pu = u * inv, pv = v * inv;
+    const uint4* rd4 = reinterpret_cast<const uint4*>(fb.kp_desc + (rbase + r) * RVO_DESC_LEN);
+    uint4 rd[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) rd[k] = rd4[k];
+    uint32_t best = NONE_KEY;
+    for (int t0 = 0; t0 < nt; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < nt) {
+        const float2 uv = s_tuv[t];
+        const double ex = (double)uv.x - pu, ey = (double)uv.y - pv;
+        const double d2 = ex * ex + ey * ey;
+        // err.norm() < window (motion_estimate.cpp:335); sqrt only in the 1e-9 band around the threshold
+        bool cand = d2 < lo2 ? true : (d2 > hi2 ? false : sqrt(d2) < win);
+        if (cand) {
+          const uint4* td4 = reinterpret_cast<const uint4*>(fb.kp_desc + (tbase + t) * RVO_DESC_LEN);
+          uint32_t s = 0;
+#pragma unroll
+          for (int k = 0; k < 5; k++) {
+            const uint4 td = td4[k];
+            s = __builtin_amdgcn_sad_u8(rd[k].x, td.x, s);
+            s = __builtin_amdgcn_sad_u8(rd[k].y, td.y, s);
+            s = __builtin_amdgcn_sad_u8(rd[k].z, td.z, s);
+            s = __builtin_amdgcn_sad_u8(rd[k].w, td.w, s);
+          }
+          // strict '<' with ascending iteration = lexicographic min of (score, index), feature.cpp:6301-6308
+          best = min(best, (s << 16) | (uint32_t)t);
+          atomicMin(&s_bt[t], (s << 16) | (uint32_t)r);
+        }
+      }
+    }
+    best = wave_min_u(best);
+    if (lane == 0) s_br[r] = best;
+  }
+  __syncthreads();
+  // mutual best matches in ref-index order, feature.cpp:6313-6333
+  int32_t* lm_ref = pb.lm_ref + (size_t)pair * g.kp_total + G.kp_off;
+  int32_t* lm_tgt = pb.lm_tgt + (size_t)pair * g.kp_total + G.kp_off;
+  int base = 0;
+  for (int c0 = 0; c0 < nr; c0 += 256) {
+    const int r = c0 + tid;
+    int flag = 0, t = 0;
+    if (r < nr) {
+      const uint32_t key = s_br[r];
+      if (key != NONE_KEY) {
+        t = key & 0xFFFF;
+        flag = (int)(s_bt[t] & 0xFFFF) == r;
+      }
+    }
+    int total;
+    const int pos = base + block_excl_scan_256(flag, s_wave, &total);
+    if (flag) { lm_ref[pos] = r; lm_tgt[pos] = t; }
+    base += total;
+  }
+  if (tid == 0) pb.lm_cnt[pair * RVO_MAX_LEVELS + lvl] = base;
+}
+
+// ------------------------------------------------------------------ sub-pixel refinement
+__device__ inline int desc_off(int i, int stride) { return (i / 9 - 4) * stride + (i % 9 - 4); }
+
+struct Wts { float wa, wb, wc, wd; int base; };
+// bilinear weights of Descriptor::ExtractInterpDescriptor, feature.cpp:6116-6124
+__device__ inline Wts make_wts(float x, float y, int stride) {
+  const int u = (int)x, v = (int)y;
+  const float wr = x - (float)u, wbm = y - (float)v;
+  Wts w;
+  w.wa = (float)((1. - (double)wr) * (1. - (double)wbm));
+  w.wb = (float)((double)wr * (1. - (double)wbm));
+  w.wc = (float)((1. - (double)wr) * (double)wbm);
+  w.wd = wr * wbm;
+  w.base = v * stride + u;
+  return w;
+}
+__device__ inline int interp_raw(const uint8_t* __restrict__ gimg, int stride, const Wts& w, int i) {
+  const int k = w.base + desc_off(i, stride);
+  const float f = ((w.wa * (float)gimg[k] + w.wb * (float)gimg[k + 1]) + w.wc * (float)gimg[k + stride]) + w.wd * (float)gimg[k + stride + 1];
+  return (int)f;  // (uint8_t) truncation; f is in [0, 256)
+}
+__device__ inline int norm_px(int v, int mean) {  // Descriptor::Normalized, feature.cpp:6158-6178
+  if (mean < 128) return min(255, v + (128 - mean));
+  if (mean > 128) return max(0, v - (mean - 128));
+  return v;
+}
+
+// grid (ceil(kp_total/128), n_pairs), 128 threads: one lane per match.
+__global__ __launch_bounds__(128) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
+  const int pair = blockIdx.y;
+  if (!pb.active[pair]) return;
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  int off[RVO_MAX_LEVELS + 1];
+  off[0] = 0;
+  for (int l = 0; l < g.levels; l++) off[l + 1] = off[l] + pb.lm_cnt[pair * RVO_MAX_LEVELS + l];
+  const int N = off[g.levels];
+  if (i == 0) pb.n_matches[pair] = N;
+  if (i >= N) return;
+  int lvl = 0;
+  for (int l = 1; l < g.levels; l++) if (i >= off[l]) lvl = l;
+  const int j = i - off[lvl];
+  const LevelGeom G = g.lv[lvl];
+  const int rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
+  const int r = pb.lm_ref[(size_t)pair * g.kp_total + G.kp_off + j];
+  const int t = pb.lm_tgt[(size_t)pair * g.kp_total + G.kp_off + j];
+  const size_t rk = (size_t)rs * g.kp_total + G.kp_off + r, tk = (size_t)ts * g.kp_total + G.kp_off + t;
+  const uint32_t rkp = fb.kp_uvs[rk], tkp = fb.kp_uvs[tk];
+  const uint8_t* __restrict__ rg = fb.img + (size_t)rs * g.img_bytes + G.img_off;
+  const uint8_t* __restrict__ tg = fb.img + (size_t)ts * g.img_bytes + G.img_off;
+  const int S = G.stride;
+
+  // ---- refineFeatureMatch, motion_estimate.cpp:757-900 (descriptors recomputed per pass instead of stored)
+  const int rbase = kp_y(rkp) * S + kp_x(rkp);
+  const float tu = (float)kp_x(tkp), tv = (float)kp_y(tkp);
+  float tx = tu, ty = tv;
+  Wts wt = make_wts(tx, ty, S);
+  int rsum = 0, tsum = 0;
+  for (int k = 0; k < RVO_DESC_LEN; k++) { rsum += rg[rbase + desc_off(k, S)]; tsum += interp_raw(tg, S, wt, k); }
+  const int rmean = rsum / RVO_DESC_LEN;
+  int tmean = tsum / RVO_DESC_LEN;
+  int final_sse = 0;
+  for (int k = 0; k < RVO_DESC_LEN; k++) {
+    const int e = norm_px(interp_raw(tg, S, wt, k), tmean) - norm_px(rg[rbase + desc_off(k, S)], rmean);
+    final_sse += e * e;
+  }
+  const int min_xy = RVO_WIN, max_x = G.w - RVO_WIN - 2, max_y = G.h - RVO_WIN - 2;  // pyramid.cpp:123-126
+  for (int it = 0; it < 6; it++) {
+    const int tc = ((int)ty) * S + (int)tx;
+    int S00 = 0, S01 = 0, S11 = 0, gxs = 0, gys = 0;
+    for (int k = 0; k < RVO_DESC_LEN; k++) {
+      const int o = desc_off(k, S);
+      const int kr = rbase + o, kt = tc + o;
+      const int r0 = rg[kr], t0 = tg[kt];
+      const int mx = (rg[kr + 1] - r0) + (tg[kt + 1] - t0);
+      const int my = (rg[kr + S] - r0) + (tg[kt + S] - t0);
+      const int e = norm_px(interp_raw(tg, S, wt, k), tmean) - norm_px(r0, rmean);
+      S00 += mx * mx; S01 += mx * my; S11 += my * my; gxs += mx * e; gys += my * e;
+    }
+    const double s00 = S00, s01 = S01, s11 = S11;
+    const double det = s00 * s11 - s01 * s01;
+    if (det <= 1e-9) break;
+    const double si00 = s11 / det, si01 = -s01 / det, si11 = s00 / det;
+    const double gx = gxs, gy = gys;
+    const double dxs = -2 * (si00 * gx + si01 * gy);
+    const double dys = -2 * (si01 * gx + si11 * gy);
+    const float ntx = (float)((double)tx + dxs), nty = (float)((double)ty + dys);
+    if (!(ntx >= (float)min_xy && ntx <= (float)max_x && nty >= (float)min_xy && nty <= (float)max_y)) break;
+    const Wts wn = make_wts(ntx, nty, S);
+    int nsum = 0;
+    for (int k = 0; k < RVO_DESC_LEN; k++) nsum += interp_raw(tg, S, wn, k);
+    const int nmean = nsum / RVO_DESC_LEN;
+    int sse = 0;
+    for (int k = 0; k < RVO_DESC_LEN; k++) {
+      const int e = norm_px(interp_raw(tg, S, wn, k), nmean) - norm_px(rg[rbase + desc_off(k, S)], rmean);
+      sse += e * e;
+    }
+    if (sse < final_sse) { tx = ntx; ty = nty; final_sse = sse; wt = wn; tmean = nmean; } else break;
+    if (fabs(dxs) < 0.1 && fabs(dys) < 0.1) break;
+  }
+
+  // ---- gating + refined record, motion_estimate.cpp:360-376
+  const double ddx = (double)tu - (double)tx, ddy = (double)tv - (double)ty;
+  const double dsn = sqrt(ddx * ddx + ddy * ddy);
+  float2 ouv = make_float2(tu, tv);
+  const float2 trect = fb.kp_rect[tk];
+  double rect0 = trect.x, rect1 = trect.y;
+  double X = fb.kp_xyz[tk * 3], Y = fb.kp_xyz[tk * 3 + 1], Z = fb.kp_xyz[tk * 3 + 2];
+  int status = RVO_MATCH_OK;
+  if (!(dsn < 1e-9) && !(dsn > 1.5)) {
+    ouv = make_float2(tx, ty);
+    const double bu = (double)tx * (double)(1 << lvl), bv = (double)ty * (double)(1 << lvl);
+    {  // Camera::BilinearLookup, camera.hpp:85-117
+      const int u = (int)bu, v = (int)bv;
+      const float wr = (float)(bu - (double)u), wb = (float)(bv - (double)v);
+      const float w[4] = {(1 - wr) * (1 - wb), wr * (1 - wb), (1 - wr) * wb, wr * wb};
+      const int ra = v * g.W + u;
+      const int idx[4] = {ra, ra + 1, ra + g.W, ra + g.W + 1};
+      rect0 = 0; rect1 = 0;
+      for (int q = 0; q < 4; q++) {
+        rect0 += (double)(w[q] * fb.xmap[idx[q]]);
+        rect1 += (double)(w[q] * fb.ymap[idx[q]]);
+      }
+    }
+    status = RVO_MATCH_REFINEMENT_FAILED;
+    {  // Depth::GetXYZInterp on the target frame's depth, depth.cpp:97-162
+      const uint16_t* __restrict__ depth = fb.depth + (size_t)ts * g.Wd * g.Hd;
+      const float u_f = (float)rect0, v_f = (float)rect1;
+      const float v_f_d = v_f * g.ys, u_f_d = u_f * g.xs;
+      const int v = (int)v_f_d, u = (int)u_f_d;
+      const float wr = u_f_d - (float)u, wb = v_f_d - (float)v;
+      if (u >= 0 && v >= 0 && u < g.Wd - 1 && v < g.Hd - 1) {
+        const float w[4] = {(1 - wr) * (1 - wb), wr * (1 - wb), (1 - wr) * wb, wr * wb};
+        const int di = v * g.Wd + u;
+        const uint16_t dr[4] = {depth[di], depth[di + 1], depth[di + g.Wd], depth[di + g.Wd + 1]};
+        const int missing = (dr[0] == 0) + (dr[1] == 0) + (dr[2] == 0) + (dr[3] == 0);
+        if (missing < 4) {
+          double z;
+          if (missing) {
+            z = NAN;  // depth.cpp:137-147 selects the NaN neighbour (isnan instead of !isnan); kept
+          } else {
+            z = 0;
+            for (int q = 0; q < 4; q++) z += (double)(float)((double)dr[q] * 1e-3) * (double)w[q];
+          }
+          X = z * ((double)u_f * g.fx_inv + g.neg_cx_div_fx);
+          Y = z * ((double)v_f * g.fy_inv + g.neg_cy_div_fy);
+          Z = z;
+          status = RVO_MATCH_OK;
+        }
+      }
+    }
+  }
+  const size_t mi = (size_t)pair * pb.mcap + i;
+  pb.m_ref[mi] = r; pb.m_tgt[mi] = t;
+  pb.m_level[mi] = (uint8_t)lvl; pb.m_status[mi] = (uint8_t)status;
+  pb.m_uv[mi] = ouv;
+  pb.m_rect[mi * 2] = rect0; pb.m_rect[mi * 2 + 1] = rect1;
+  pb.m_xyz[mi * 3] = X; pb.m_xyz[mi * 3 + 1] = Y; pb.m_xyz[mi * 3 + 2] = Z;
+  // reference-side fields gathered once for the consistency / GN stages
+  const float2 rrect = fb.kp_rect[rk];
+  pb.m_rrect[mi * 2] = rrect.x; pb.m_rrect[mi * 2 + 1] = rrect.y;
+  pb.m_rxyz[mi * 3] = fb.kp_xyz[rk * 3]; pb.m_rxyz[mi * 3 + 1] = fb.kp_xyz[rk * 3 + 1]; pb.m_rxyz[mi * 3 + 2] = fb.kp_xyz[rk * 3 + 2];
+  pb.m_inlier[mi] = 0;
+  pb.m_reproj[mi] = 0;
+}
+
+// ------------------------------------------------------------------ consistency matrix
+// grid (ceil(mcap/256), n_pairs), 256 threads: lane = row i; columns visited uniformly per wave.
+__global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) {
+  const int pair = blockIdx.y;
+  if (!pb.active[pair]) return;
+  const int N = pb.n_matches[pair];
+  const int wave_row0 = blockIdx.x * 256 + (threadIdx.x & ~63);
+  if (wave_row0 >= N) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < N;
+  const size_t mb = (size_t)pair * pb.mcap;
+  const int ii = live ? i : N - 1;
+  const double r1x = pb.m_rxyz[(mb + ii) * 3], r1y = pb.m_rxyz[(mb + ii) * 3 + 1], r1z = pb.m_rxyz[(mb + ii) * 3 + 2];
+  const double t1x = pb.m_xyz[(mb + ii) * 3], t1y = pb.m_xyz[(mb + ii) * 3 + 1], t1z = pb.m_xyz[(mb + ii) * 3 + 2];
+  const double thr = ep.clique_inlier_threshold;
+  uint32_t* row = pb.cbits + (mb + ii) * pb.cwords;
+  int degree = 0;
+  const int nw = (N + 31) >> 5;
+  for (int wj = 0; wj < nw; wj++) {
+    uint32_t word = 0;
+    const int jend = min(32, N - wj * 32);
+    for (int b = 0; b < jend; b++) {
+      const int j = wj * 32 + b;  // wave-uniform: scalar loads
+      const double* rj = pb.m_rxyz + (mb + j) * 3;
+      const double* tj = pb.m_xyz + (mb + j) * 3;
+      // (ref_xyz_2 - ref_xyz_1).norm() with Eigen 3.2's x*x + (y*y + z*z); motion_estimate.cpp:505-507
+      double dx = rj[0] - r1x, dy = rj[1] - r1y, dz = rj[2] - r1z;
+      const double rd = sqrt(dx * dx + (dy * dy + dz * dz));
+      dx = tj[0] - t1x; dy = tj[1] - t1y; dz = tj[2] - t1z;
+      const double td = sqrt(dx * dx + (dy * dy + dz * dz));
+      const bool c = (fabs(rd - td) < thr) && (j != i);
+      word |= (uint32_t)c << b;
+    }
+    degree += __popc(word);
+    if (live) row[wj] = word;
+  }
+  if (live) pb.m_degree[mb + i] = degree;
+}
+
+// ------------------------------------------------------------------ sort + greedy clique
+// grid (n_pairs), 64 threads (one wave); dynamic LDS = mcap*4 + cwords*4 + 512.
+__global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const int pair = blockIdx.x, lane = threadIdx.x;
+  if (!pb.active[pair]) return;
+  uint32_t* keys = reinterpret_cast<uint32_t*>(lds);
+  uint32_t* acc = keys + pb.mcap;
+  int* stack = reinterpret_cast<int*>(acc + pb.cwords);
+  const int N = pb.n_matches[pair];
+  const size_t mb = (size_t)pair * pb.mcap;
+  rvo_pair_result* res = pb.result + pair;
+  if (N == 0) {  // computeMaximallyConsistentClique returns early (motion_estimate.cpp:444-445); 0 inliers
+    if (lane == 0) res->num_inliers = 0;
+    return;
+  }
+  for (int i = lane; i < N; i += 64) keys[i] = ((uint32_t)pb.m_degree[mb + i] << 16) | (uint32_t)i;
+  const int nw = (N + 31) >> 5;
+  for (int w = lane; w < nw; w += 64) acc[w] = 0;
+  __syncthreads();
+  // std::sort(_matches, _matches+N, consistencyCompare): unstable, replayed exactly
+  if (lane == 0) stdalgo::sort(keys, N, [](uint32_t a, uint32_t b) { return (a >> 16) > (b >> 16); }, stack);
+  __syncthreads();
+  for (int i = lane; i < N; i += 64) pb.order[mb + i] = keys[i];
+
+  // greedy clique, motion_estimate.cpp:529-569, 64 candidates per round
+  int num_inl = 0;
+  bool stop = false;
+  for (int c0 = 0; c0 < N && !stop; c0 += 64) {
+    const int m = c0 + lane;
+    const bool valid = m < N;
+    const uint32_t key = valid ? keys[m] : 0;
+    const int id = key & 0xFFFF, deg = (int)(key >> 16);
+    const uint32_t* __restrict__ row = pb.cbits + (mb + id) * pb.cwords;
+    bool ok = valid;
+    if (valid)
+      for (int w = 0; w < nw; w++)
+        if (acc[w] & ~row[w]) { ok = false; break; }
+    unsigned long long cm = 0;
+    const int kmax = min(64, N - c0);
+    for (int k = 0; k < kmax; k++) {
+      const int idk = __shfl(id, k, 64);
+      if (valid) cm |= (unsigned long long)((row[idk >> 5] >> (idk & 31)) & 1u) << k;
+    }
+    for (int k = 0; k < kmax; k++) {
+      const int degk = __shfl(deg, k, 64);
+      const int okk = __shfl((int)ok, k, 64);
+      if (degk < num_inl) { stop = true; break; }
+      if (okk) {
+        num_inl++;
+        if (lane == k) {
+          acc[id >> 5] |= 1u << (id & 31);
+          pb.m_inlier[mb + id] = 1;
+        }
+        ok = ok && ((cm >> k) & 1ull);
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) res->num_inliers = num_inl;
+}
+
+// ------------------------------------------------------------------ Gauss-Newton + status
+struct JacMats { double P[12], Ju[24], Jv[24], Jw[24]; };
+
+// computeProjectionJacobian, motion_estimate.cpp:1061-1101
+__device__ inline void forward_jac_mats(const double* prm, double fx, double px, double py, JacMats& m) {
+  const double tx = prm[0], ty = prm[1], tz = prm[2];
+  const double sr = sin(prm[3]), cr = cos(prm[3]), sp = sin(prm[4]), cp = cos(prm[4]), sy = sin(prm[5]), cy = cos(prm[5]);
+  const double P[12] = {fx * cp * cy - px * sp, px * cp * sr - fx * (cr * sy - cy * sp * sr), fx * (sr * sy + cr * cy * sp) + px * cp * cr, fx * tx + px * tz,
+                        fx * cp * sy - py * sp, fx * (cr * cy + sp * sr * sy) + py * cp * sr, py * cp * cr - fx * (cy * sr - cr * sp * sy), fx * ty + py * tz,
+                        -sp, cp * sr, cp * cr, tz};
+  const double Ju[24] = {0, 0, 0, fx,
+                         0, 0, 0, 0,
+                         0, 0, 0, px,
+                         0, fx * (sr * sy + cr * cy * sp) + px * cp * cr, fx * (cr * sy - cy * sp * sr) - px * cp * sr, 0,
+                         -px * cp - fx * cy * sp, -sr * (px * sp - fx * cp * cy), -cr * (px * sp - fx * cp * cy), 0,
+                         -fx * cp * sy, -fx * cr * cy - fx * sp * sr * sy, fx * cy * sr - fx * cr * sp * sy, 0};
+  const double Jv[24] = {0, 0, 0, 0,
+                         0, 0, 0, fx,
+                         0, 0, 0, py,
+                         0, py * cp * cr - fx * (cy * sr - cr * sp * sy), -fx * (cr * cy + sp * sr * sy) - py * cp * sr, 0,
+                         -py * cp - fx * sp * sy, -sr * (py * sp - fx * cp * sy), -cr * (py * sp - fx * cp * sy), 0,
+                         fx * cp * cy, fx * cy * sp * sr - fx * cr * sy, fx * sr * sy + fx * cr * cy * sp, 0};
+  const double Jw[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, cp * cr, -cp * sr, 0, -cp, -sp * sr, -cr * sp, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 12; i++) m.P[i] = P[i];
+  for (int i = 0; i < 24; i++) { m.Ju[i] = Ju[i]; m.Jv[i] = Jv[i]; m.Jw[i] = Jw[i]; }
+}
+
+// computeReverseProjectionJacobian, motion_estimate.cpp:1133-1184
+__device__ inline void reverse_jac_mats(const double* prm, double fx, double px, double py, JacMats& m) {
+  const double tx = prm[0], ty = prm[1], tz = prm[2];
+  const double sr = sin(prm[3]), cr = cos(prm[3]), sp = sin(prm[4]), cp = cos(prm[4]), sy = sin(prm[5]), cy = cos(prm[5]);
+  const double P[12] = {
+      px * (sr * sy + cr * cy * sp) + fx * cp * cy, fx * cp * sy - px * (cy * sr - cr * sp * sy), px * cp * cr - fx * sp,
+      -px * (tx * (sr * sy + cr * cy * sp) - ty * (cy * sr - cr * sp * sy) + tz * cp * cr) - fx * (tx * cp * cy - tz * sp + ty * cp * sy),
+      py * (sr * sy + cr * cy * sp) - fx * (cr * sy - cy * sp * sr), fx * (cr * cy + sp * sr * sy) - py * (cy * sr - cr * sp * sy), cp * (py * cr + fx * sr),
+      -py * (tx * (sr * sy + cr * cy * sp) - ty * (cy * sr - cr * sp * sy) + tz * cp * cr) - fx * (ty * (cr * cy + sp * sr * sy) - tx * (cr * sy - cy * sp * sr) + tz * cp * sr),
+      sr * sy + cr * cy * sp, cr * sp * sy - cy * sr, cp * cr, ty * (cy * sr - cr * sp * sy) - tx * (sr * sy + cr * cy * sp) - tz * cp * cr};
+  const double Ju[24] = {
+      0, 0, 0, -px * (sr * sy + cr * cy * sp) - fx * cp * cy,
+      0, 0, 0, px * (cy * sr - cr * sp * sy) - fx * cp * sy,
+      0, 0, 0, fx * sp - px * cp * cr,
+      px * cr * sy - px * cy * sp * sr, -px * cr * cy - px * sp * sr * sy, -px * cp * sr, px * ty * (cr * cy + sp * sr * sy) - px * tx * (cr * sy - cy * sp * sr) + px * tz * cp * sr,
+      -cy * (fx * sp - px * cp * cr), -sy * (fx * sp - px * cp * cr), -fx * cp - px * cr * sp, fx * (tz * cp + tx * cy * sp + ty * sp * sy) - px * (tx * cp * cr * cy - tz * cr * sp + ty * cp * cr * sy),
+      px * (cy * sr - cr * sp * sy) - fx * cp * sy, px * (sr * sy + cr * cy * sp) + fx * cp * cy, 0, -fx * (ty * cp * cy - tx * cp * sy) - px * (tx * (cy * sr - cr * sp * sy) + ty * (sr * sy + cr * cy * sp))};
+  const double Jv[24] = {
+      0, 0, 0, fx * (cr * sy - cy * sp * sr) - py * (sr * sy + cr * cy * sp),
+      0, 0, 0, py * (cy * sr - cr * sp * sy) - fx * (cr * cy + sp * sr * sy),
+      0, 0, 0, -cp * (py * cr + fx * sr),
+      fx * (sr * sy + cr * cy * sp) + py * (cr * sy - cy * sp * sr), -fx * (cy * sr - cr * sp * sy) - py * (cr * cy + sp * sr * sy), cp * (fx * cr - py * sr),
+      py * (ty * (cr * cy + sp * sr * sy) - tx * (cr * sy - cy * sp * sr) + tz * cp * sr) - fx * (tx * (sr * sy + cr * cy * sp) - ty * (cy * sr - cr * sp * sy) + tz * cp * cr),
+      cp * cy * (py * cr + fx * sr), cp * sy * (py * cr + fx * sr), -sp * (py * cr + fx * sr), -(py * cr + fx * sr) * (tx * cp * cy - tz * sp + ty * cp * sy),
+      py * (cy * sr - cr * sp * sy) - fx * (cr * cy + sp * sr * sy), py * (sr * sy + cr * cy * sp) - fx * (cr * sy - cy * sp * sr), 0,
+      fx * (tx * (cr * cy + sp * sr * sy) + ty * (cr * sy - cy * sp * sr)) - py * (tx * (cy * sr - cr * sp * sy) + ty * (sr * sy + cr * cy * sp))};
+  const double Jw[24] = {
+      0, 0, 0, -sr * sy - cr * cy * sp,
+      0, 0, 0, cy * sr - cr * sp * sy,
+      0, 0, 0, -cp * cr,
+      cr * sy - cy * sp * sr, -cr * cy - sp * sr * sy, -cp * sr, ty * (cr * cy + sp * sr * sy) - tx * (cr * sy - cy * sp * sr) + tz * cp * sr,
+      cp * cr * cy, cp * cr * sy, -cr * sp, -cr * (tx * cp * cy - tz * sp + ty * cp * sy),
+      cy * sr - cr * sp * sy, sr * sy + cr * cy * sp, 0, -tx * (cy * sr - cr * sp * sy) - ty * (sr * sy + cr * cy * sp)};
+  for (int i = 0; i < 12; i++) m.P[i] = P[i];
+  for (int i = 0; i < 24; i++) { m.Ju[i] = Ju[i]; m.Jv[i] = Jv[i]; m.Jw[i] = Jw[i]; }
+}
+
+// 6x6 inverse by Gaussian elimination with partial pivoting (stand-in for Eigen's PartialPivLU inverse)
+__device__ inline void inverse6(const double* A, double* inv) {
+  double a[6][12];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) { a[i][j] = A[i * 6 + j]; a[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < 6; c++) {
+    int piv = c;
+    double best = fabs(a[c][c]);
+    for (int r = c + 1; r < 6; r++) if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
+    if (piv != c) for (int j = 0; j < 12; j++) { const double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+    const double d = a[c][c];
+    for (int r = c + 1; r < 6; r++) {
+      const double f = a[r][c] / d;
+      for (int j = c; j < 12; j++) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int c = 5; c >= 0; c--) {
+    const double d = a[c][c];
+    for (int j = 6; j < 12; j++) {
+      double s = a[c][j];
+      for (int k = c + 1; k < 6; k++) s -= a[c][k] * a[k][j];
+      a[c][j] = s / d;
+    }
+  }
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) inv[i * 6 + j] = a[i][6 + j];
+}
+
+struct GnShared {
+  JacMats fwd, rev;
+  double Pf[12], Pr[12];   // K(fx,fx)*motion and K(fx,fx)*motion^-1 for the error at the current estimate
+  double Pnf[12], Pnr[12]; // same at the trial estimate
+  double red[28 * 4];
+  double est[6], next[6], delta[6];
+  double motion[12], nmotion[12];
+  double final_sse;
+  int stop, status, n_inl;
+};
+
+// grid (n_pairs), 256 threads.
+__global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParams ep) {
+  __shared__ GnShared S;
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  if (!pb.active[pair]) return;
+  const int N = pb.n_matches[pair];
+  const size_t mb = (size_t)pair * pb.mcap;
+  rvo_pair_result* res = pb.result + pair;
+  const double fx = cam.fx, px = cam.cx, py = cam.cy;
+
+  if (tid == 0) {
+    S.n_inl = res->num_inliers;
+    S.status = RVO_SUCCESS;  // motion_estimate.cpp:190-192
+    for (int k = 0; k < 12; k++) S.motion[k] = pb.init_pose[pair * 12 + k];
+    for (int k = 0; k < 36; k++) res->cov[k] = 0;
+  }
+  __syncthreads();
+
+  auto err_sse = [&](const double* Pf, const double* Pr) -> double {  // sum of squared bidirectional errors over inliers
+    double s = 0;
+    for (int i = tid; i < N; i += 256) {
+      if (!pb.m_inlier[mb + i]) continue;
+      const double* t = pb.m_xyz + (mb + i) * 3;
+      const double* r = pb.m_rxyz + (mb + i) * 3;
+      double u = dot4(Pf, t[0], t[1], t[2], 1.0), v = dot4(Pf + 4, t[0], t[1], t[2], 1.0), w = dot4(Pf + 8, t[0], t[1], t[2], 1.0);
+      double e0 = u / w - pb.m_rrect[(mb + i) * 2], e1 = v / w - pb.m_rrect[(mb + i) * 2 + 1];
+      s += e0 * e0; s += e1 * e1;
+      u = dot4(Pr, r[0], r[1], r[2], 1.0); v = dot4(Pr + 4, r[0], r[1], r[2], 1.0); w = dot4(Pr + 8, r[0], r[1], r[2], 1.0);
+      e0 = u / w - pb.m_rect[(mb + i) * 2]; e1 = v / w - pb.m_rect[(mb + i) * 2 + 1];
+      s += e0 * e0; s += e1 * e1;
+    }
+    return s;
+  };
+  auto set_P = [&](const DIso& m, double* Pf, double* Pr) {
+    proj_matrix(fx, fx, px, py, m, Pf);  // fx on both axes, motion_estimate.cpp:1221-1223
+    proj_matrix(fx, fx, px, py, iso_inverse(m), Pr);
+  };
+
+  // refineMotionEstimate() -> refineMotionEstimateBidirectional, motion_estimate.cpp:610-682, 1208-1331
+  auto refine = [&]() {
+    __syncthreads();
+    if (S.n_inl < ep.min_features) {
+      if (tid == 0) S.status = RVO_INSUFFICIENT_INLIERS;
+      __syncthreads();
+      return;
+    }
+    if (tid == 0) {
+      DIso m;
+      iso_load(m, S.motion);
+      iso_to_params(m, S.est);
+      set_P(m, S.Pf, S.Pr);
+      S.stop = 0;
+    }
+    __syncthreads();
+    {
+      double v[1] = {err_sse(S.Pf, S.Pr)};
+      block_sum_d<1>(v, S.red);
+      if (tid == 0) S.final_sse = v[0];
+    }
+    for (int it = 0; it < 6; it++) {
+      if (tid == 0) forward_jac_mats(S.est, fx, px, py, S.fwd);
+      if (tid == 64) reverse_jac_mats(S.est, fx, px, py, S.rev);
+      __syncthreads();
+      double acc[27];
+#pragma unroll
+      for (int k = 0; k < 27; k++) acc[k] = 0;
+      for (int i = tid; i < N; i += 256) {
+        if (!pb.m_inlier[mb + i]) continue;
+#pragma unroll
+        for (int dir = 0; dir < 2; dir++) {
+          const JacMats& J = dir ? S.rev : S.fwd;
+          const double* Pe = dir ? S.Pr : S.Pf;
+          const double* pt = (dir ? pb.m_rxyz : pb.m_xyz) + (mb + i) * 3;
+          const double* pj = (dir ? pb.m_rect : pb.m_rrect) + (mb + i) * 2;
+          const double x = pt[0], y = pt[1], z = pt[2];
+          const double u = dot4(J.P, x, y, z, 1.0), v = dot4(J.P + 4, x, y, z, 1.0), w = dot4(J.P + 8, x, y, z, 1.0);
+          const double w_inv_sq = 1 / (w * w);
+          double ru[6], rv[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) {
+            const double du = dot4(J.Ju + 4 * k, x, y, z, 1.0), dv = dot4(J.Jv + 4 * k, x, y, z, 1.0), dw = dot4(J.Jw + 4 * k, x, y, z, 1.0);
+            ru[k] = (du * w - dw * u) * w_inv_sq;
+            rv[k] = (dv * w - dw * v) * w_inv_sq;
+          }
+          const double eu = dot4(Pe, x, y, z, 1.0), ev = dot4(Pe + 4, x, y, z, 1.0), ew = dot4(Pe + 8, x, y, z, 1.0);
+          const double e0 = eu / ew - pj[0], e1 = ev / ew - pj[1];
+          int q = 0;
+#pragma unroll
+          for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int b = a; b < 6; b++) { acc[q] += ru[a] * ru[b]; acc[q] += rv[a] * rv[b]; q++; }
+            acc[21 + a] += ru[a] * e0;
+            acc[21 + a] += rv[a] * e1;
+          }
+        }
+      }
+      block_sum_d<27>(acc, S.red);
+      if (tid == 0) {
+        double A[36], Ainv[36], delta[6], next[6];
+        int q = 0;
+        for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { A[a * 6 + b] = acc[q]; A[b * 6 + a] = acc[q]; q++; }
+        inverse6(A, Ainv);
+        for (int a = 0; a < 6; a++) {
+          double s = 0;
+          for (int b = 0; b < 6; b++) s += (-Ainv[a * 6 + b]) * acc[21 + b];
+          delta[a] = s;
+          next[a] = S.est[a] + s;
+        }
+        const DIso nest = iso_from_params(next);
+        set_P(nest, S.Pnf, S.Pnr);
+        for (int a = 0; a < 6; a++) { S.next[a] = next[a]; S.delta[a] = delta[a]; }
+        iso_store(nest, S.nmotion);
+      }
+      __syncthreads();
+      double v[1] = {err_sse(S.Pnf, S.Pnr)};
+      block_sum_d<1>(v, S.red);
+      if (tid == 0) {
+        const double sse = v[0];
+        if (sse > S.final_sse) {
+          S.stop = 1;
+        } else {
+          for (int a = 0; a < 6; a++) S.est[a] = S.next[a];
+          S.final_sse = sse;
+          for (int k = 0; k < 12; k++) { S.motion[k] = S.nmotion[k]; S.Pf[k] = S.Pnf[k]; S.Pr[k] = S.Pnr[k]; }
+          const double rt = 0.01 * M_PI / 180;
+          const double* d = S.delta;
+          if (fabs(d[0]) < 0.0001 && fabs(d[1]) < 0.0001 && fabs(d[2]) < 0.0001 && fabs(d[3]) < rt && fabs(d[4]) < rt && fabs(d[5]) < rt) S.stop = 1;
+        }
+      }
+      __syncthreads();
+      if (S.stop) break;
+    }
+    // covariance = (M'M)^-1 at the final parameters, motion_estimate.cpp:1319-1329
+    __syncthreads();
+    if (tid == 0) forward_jac_mats(S.est, fx, px, py, S.fwd);
+    if (tid == 64) reverse_jac_mats(S.est, fx, px, py, S.rev);
+    __syncthreads();
+    double acc[21];
+#pragma unroll
+    for (int k = 0; k < 21; k++) acc[k] = 0;
+    for (int i = tid; i < N; i += 256) {
+      if (!pb.m_inlier[mb + i]) continue;
+#pragma unroll
+      for (int dir = 0; dir < 2; dir++) {
+        const JacMats& J = dir ? S.rev : S.fwd;
+        const double* pt = (dir ? pb.m_rxyz : pb.m_xyz) + (mb + i) * 3;
+        const double x = pt[0], y = pt[1], z = pt[2];
+        const double u = dot4(J.P, x, y, z, 1.0), v = dot4(J.P + 4, x, y, z, 1.0), w = dot4(J.P + 8, x, y, z, 1.0);
+        const double w_inv_sq = 1 / (w * w);
+        double ru[6], rv[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const double du = dot4(J.Ju + 4 * k, x, y, z, 1.0), dv = dot4(J.Jv + 4 * k, x, y, z, 1.0), dw = dot4(J.Jw + 4 * k, x, y, z, 1.0);
+          ru[k] = (du * w - dw * u) * w_inv_sq;
+          rv[k] = (dv * w - dw * v) * w_inv_sq;
+        }
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b = a; b < 6; b++) { acc[q] += ru[a] * ru[b]; acc[q] += rv[a] * rv[b]; q++; }
+      }
+    }
+    block_sum_d<21>(acc, S.red);
+    if (tid == 0) {
+      double A[36], Ainv[36];
+      int q = 0;
+      for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { A[a * 6 + b] = acc[q]; A[b * 6 + a] = acc[q]; q++; }
+      inverse6(A, Ainv);
+      for (int k = 0; k < 36; k++) res->cov[k] = Ainv[k];
+    }
+    __syncthreads();
+  };
+
+  // computeReprojectionError(), motion_estimate.cpp:684-720 (K uses fx, fy)
+  __shared__ double s_mean;
+  if (tid == 0) s_mean = 0;
+  auto reproj = [&]() {
+    __syncthreads();
+    if (S.status != RVO_SUCCESS) return;
+    if (tid == 0) {
+      DIso m;
+      iso_load(m, S.motion);
+      proj_matrix(cam.fx, cam.fy, cam.cx, cam.cy, m, S.Pnf);
+    }
+    __syncthreads();
+    double v[1] = {0};
+    for (int i = tid; i < N; i += 256) {
+      if (!pb.m_inlier[mb + i]) continue;
+      const double* t = pb.m_xyz + (mb + i) * 3;
+      const double h0 = dot4(S.Pnf, t[0], t[1], t[2], 1.0), h1 = dot4(S.Pnf + 4, t[0], t[1], t[2], 1.0), h2 = dot4(S.Pnf + 8, t[0], t[1], t[2], 1.0);
+      const double ex = pb.m_rrect[(mb + i) * 2] - h0 / h2, ey = pb.m_rrect[(mb + i) * 2 + 1] - h1 / h2;
+      const double e = sqrt(ex * ex + ey * ey);
+      pb.m_reproj[mb + i] = e;
+      v[0] += e;
+    }
+    block_sum_d<1>(v, S.red);
+    if (tid == 0) s_mean = v[0] / (double)S.n_inl;
+    __syncthreads();
+  };
+
+  refine();
+  reproj();
+  // drop inliers with a high reprojection error, motion_estimate.cpp:203-214
+  {
+    __syncthreads();
+    int fails = 0;
+    for (int i = tid; i < N; i += 256)
+      if (pb.m_inlier[mb + i] && pb.m_reproj[mb + i] > ep.inlier_max_reprojection_error) { pb.m_inlier[mb + i] = 0; fails++; }
+    double v[1] = {(double)fails};
+    block_sum_d<1>(v, S.red);
+    if (tid == 0) { S.n_inl -= (int)v[0]; res->num_reprojection_failures = (int)v[0]; }
+    __syncthreads();
+  }
+  refine();
+  reproj();
+  __syncthreads();
+  if (tid == 0) {
+    int status = S.status;
+    if (s_mean > ep.max_mean_reprojection_error) status = RVO_REPROJECTION_ERROR;
+    res->status = status;
+    res->num_matches = N;
+    res->num_inliers = S.n_inl;
+    res->mean_reprojection_error = s_mean;
+    for (int k = 0; k < 12; k++) res->pose[k] = S.motion[k];
+  }
+}
+
+// ------------------------------------------------------------------ streaming state machine (vo.cpp:55-165)
+struct StreamState {
+  int init_cnt, frame_cnt, ref_changed_flag, fast_thr;
+  int slot_ref, slot_prev, slot_curr;
+  int ref_changed;  // this step's copy of the flag (vo.cpp:78)
+  int processed;    // past warm-up this step
+  int estimate;     // frame_cnt >= 2 this step
+  int retry;        // fallback vs previous frame pending
+  int pad_;
+  double pose[12], ref_to_prev[12], curr_to_prev[12], curr_to_ref[12];
+  double cov[36];
+};
+
+struct StreamParams {
+  int warmup, thr_init, thr_min, thr_max, target_num_features, keyframe_thr;
+  double gain;
+};
+
+__device__ inline void iso_set_identity12(double* p) { for (int k = 0; k < 12; k++) p[k] = (k % 5 == 0) ? 1.0 : 0.0; }
+
+__global__ void k_stream_reset(StreamState* st, rvo_stream_result* out, int n, StreamParams sp) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  StreamState& S = st[s];
+  S.init_cnt = 0; S.frame_cnt = 0; S.ref_changed_flag = 0; S.fast_thr = sp.thr_init;
+  S.slot_ref = 3 * s; S.slot_prev = 3 * s + 1; S.slot_curr = 3 * s + 2;
+  S.ref_changed = 0; S.processed = 0; S.estimate = 0; S.retry = 0; S.pad_ = 0;
+  iso_set_identity12(S.pose); iso_set_identity12(S.ref_to_prev); iso_set_identity12(S.curr_to_prev); iso_set_identity12(S.curr_to_ref);
+  for (int k = 0; k < 36; k++) S.cov[k] = 0;
+  memset(&out[s], 0, sizeof(rvo_stream_result));
+  iso_set_identity12(out[s].pose); iso_set_identity12(out[s].curr_to_ref);
+  out[s].fast_threshold = sp.thr_init;
+}
+
+// vo.cpp:58-80: warm-up skip, buffer rotation; emits the slot/threshold the frame kernels use (-1 = skip)
+__global__ void k_stream_pre(StreamState* st, int n, StreamParams sp, int32_t* sslots /*[2n]: slot, thr*/, PairBufs pb) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  StreamState& S = st[s];
+  S.processed = 0; S.estimate = 0; S.retry = 0;
+  pb.active[s] = 0;
+  sslots[s] = -1;
+  sslots[n + s] = S.fast_thr;
+  if (S.init_cnt < sp.warmup) {
+    ++S.init_cnt;
+    if (S.init_cnt != sp.warmup) return;
+  }
+  S.processed = 1;
+  if (S.ref_changed_flag) {
+    const int t = S.slot_ref; S.slot_ref = S.slot_curr; S.slot_curr = t;
+    iso_set_identity12(S.ref_to_prev);
+  } else {
+    const int t = S.slot_prev; S.slot_prev = S.slot_curr; S.slot_curr = t;
+  }
+  S.ref_changed = S.ref_changed_flag;
+  S.ref_changed_flag = 0;
+  iso_set_identity12(S.curr_to_prev);
+  sslots[s] = S.slot_curr;
+}
+
+// vo.cpp:92-110: adaptive FAST threshold, first-frame handling, choice of the initial-rotation source
+__global__ void k_stream_mid(StreamState* st, int n, StreamParams sp, FrameBufs fb, FrameGeom g, PairBufs pb) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  StreamState& S = st[s];
+  if (!S.processed) return;
+  int det = 0;
+  for (int l = 0; l < g.levels; l++) det += fb.det_cnt[S.slot_curr * RVO_MAX_LEVELS + l];
+  const int err = det - sp.target_num_features;
+  const int adjust = (int)((double)err * sp.gain);
+  S.fast_thr += adjust;
+  S.fast_thr = min(S.fast_thr, sp.thr_max);
+  S.fast_thr = max(S.fast_thr, sp.thr_min);
+  ++S.frame_cnt;
+  if (S.frame_cnt < 2) { S.ref_changed_flag = 1; return; }
+  S.estimate = 1;
+  pb.active[s] = 1;
+  pb.ref_slot[s] = S.slot_ref;
+  pb.tgt_slot[s] = S.slot_curr;
+  pb.rot_slot[s] = S.ref_changed ? S.slot_ref : S.slot_prev;
+}
+
+// vo.cpp:113-115: initial estimate = ref_to_prev^-1 rotated by the initial rotation
+__global__ void k_stream_init(StreamState* st, int n, PairBufs pb) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  StreamState& S = st[s];
+  if (!S.estimate) return;
+  DIso r2p;
+  iso_load(r2p, S.ref_to_prev);
+  DIso init = iso_inverse(r2p);
+  const double* q = pb.q0 + s * 4;
+  iso_rotate(init, DQuat{q[0], q[1], q[2], q[3]});
+  iso_store(init, pb.init_pose + s * 12);
+}
+
+// vo.cpp:124-143: accept the estimate vs the reference frame, or arm the retry vs the previous frame
+__global__ void k_stream_post1(StreamState* st, int n, PairBufs pb) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  StreamState& S = st[s];
+  if (!S.estimate) return;
+  pb.active[s] = 0;
+  const rvo_pair_result& r = pb.result[s];
+  if (r.status == RVO_SUCCESS) {
+    DIso to_ref, r2p, pose;
+    iso_load(to_ref, r.pose); iso_load(r2p, S.ref_to_prev); iso_load(pose, S.pose);
+    iso_store(to_ref, S.curr_to_ref);
+    const DIso c2p = iso_mul(r2p, to_ref);
+    iso_store(c2p, S.curr_to_prev);
+    for (int k = 0; k < 36; k++) S.cov[k] = r.cov[k];
+    iso_store(iso_inverse(to_ref), S.ref_to_prev);
+    iso_store(iso_mul(pose, c2p), S.pose);
+  } else if (!S.ref_changed) {
+    S.retry = 1;
+    DIso init;
+    iso_identity(init);
+    const double* q = pb.q0 + s * 4;
+    iso_rotate(init, DQuat{q[0], q[1], q[2], q[3]});
+    iso_store(init, pb.init_pose + s * 12);
+    pb.ref_slot[s] = S.slot_prev;
+    pb.active[s] = 1;
+  }
+}
+
+// vo.cpp:145-163: retry result, failure report, keyframe decision; fills the per-stream result record
+__global__ void k_stream_post2(StreamState* st, int n, StreamParams sp, PairBufs pb, rvo_stream_result* out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  StreamState& S = st[s];
+  rvo_stream_result& o = out[s];
+  o.used_fallback = 0;
+  if (!S.processed) { o.rc = 0; o.fast_threshold = S.fast_thr; o.keyframe_changed = S.ref_changed_flag; return; }
+  o.rc = 1;
+  if (S.estimate) {
+    const rvo_pair_result& r = pb.result[s];
+    if (S.retry && r.status == RVO_SUCCESS) {
+      DIso c2p, pose, r2p;
+      iso_load(c2p, r.pose); iso_load(pose, S.pose); iso_load(r2p, S.ref_to_prev);
+      iso_store(c2p, S.curr_to_prev);
+      iso_store(iso_mul(pose, c2p), S.pose);
+      S.ref_changed_flag = 1;
+      iso_store(iso_mul(iso_inverse(r2p), c2p), S.curr_to_ref);
+      o.used_fallback = 1;
+    }
+    if (r.status != RVO_SUCCESS) {
+      o.rc = -1;  // the reference prints "Cannot get valid motion estimation" and exit(-1)s here
+    } else if (r.num_inliers < sp.keyframe_thr) {
+      S.ref_changed_flag = 1;  // vo.cpp:160-163 (threshold = option value; the reference member is uninitialised)
+    }
+    o.status = r.status; o.num_matches = r.num_matches; o.num_inliers = r.num_inliers;
+  } else {
+    o.status = RVO_NO_DATA; o.num_matches = 0; o.num_inliers = 0;
+  }
+  for (int k = 0; k < 12; k++) { o.pose[k] = S.pose[k]; o.curr_to_ref[k] = S.curr_to_ref[k]; }
+  for (int k = 0; k < 36; k++) o.cov[k] = S.cov[k];
+  o.fast_threshold = S.fast_thr;
+  o.keyframe_changed = S.ref_changed_flag;
+}

@@ -54,7 +54,10 @@ struct rvo_ctx {
   StreamState* d_streams = nullptr;
   rvo_stream_result* d_stream_res = nullptr;
   int n_streams = 0;
-  int32_t* d_sslots = nullptr;  // [n][4]: curr, ref, prev, thr  (device-written)
+  int32_t* d_sslots = nullptr;  // [2n]: current slot (-1 = warm-up skip), FAST threshold (device-written)
+  int32_t* d_pargs = nullptr;
+  double* d_pinit = nullptr;
+  int lds_rot = 0, lds_match = 0, lds_clique = 0;
   // profiling
   bool prof = false;
   std::vector<std::string> prof_names;
@@ -271,6 +274,27 @@ int rvo_sync(rvo_ctx* c) {
   return RVO_OK;
 }
 
+static int ensure_stage(rvo_ctx* c, int n) {
+  const FrameGeom& g = c->g;
+  if (c->stage_frames >= (size_t)n) return RVO_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->d_gray_stage) (void)hipFree(c->d_gray_stage);
+  if (c->d_depth_stage) (void)hipFree(c->d_depth_stage);
+  c->d_gray_stage = nullptr; c->d_depth_stage = nullptr; c->stage_frames = 0;
+  HIPCHK(hipMalloc((void**)&c->d_gray_stage, (size_t)n * g.W * g.H));
+  HIPCHK(hipMalloc((void**)&c->d_depth_stage, (size_t)n * g.Wd * g.Hd * 2));
+  c->stage_frames = n;
+  return RVO_OK;
+}
+
+static int launch_ingest(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots) {
+  const FrameGeom& g = c->g;
+  const bool vec = (g.W % 16 == 0) && (((size_t)g.Wd * g.Hd) % 8 == 0) && (((uintptr_t)gray & 15) == 0) && (((uintptr_t)depth & 15) == 0);
+  if (vec) LAUNCH(c, "ingest", k_ingest<true>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots);
+  else LAUNCH(c, "ingest", k_ingest<false>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots);
+  return RVO_OK;
+}
+
 // ---------------------------------------------------------------- PrepareFrame
 // enqueue the frame kernels for n frames whose slots/thresholds are at d_slots/d_thr (device)
 static int enqueue_prepare(rvo_ctx* c, int n, const int32_t* d_slots, const int32_t* d_thr) {
@@ -297,13 +321,7 @@ int rvo_prepare_frames_dev(rvo_ctx* c, int n, const uint8_t* gray, const uint16_
   memcpy(args.data(), slots, n * 4);
   memcpy(args.data() + n, thr, n * 4);
   HIPCHK(hipMemcpyAsync(c->d_fargs, args.data(), args.size() * 4, hipMemcpyHostToDevice, c->stream));
-  // level-0 copy (frame.cpp:47-50) and raw depth into the slots
-  for (int i = 0; i < n; i++) {
-    uint8_t* dst = c->fb.img + (size_t)slots[i] * g.img_bytes + g.lv[0].img_off;
-    HIPCHK(hipMemcpy2DAsync(dst, g.lv[0].stride, gray + (size_t)i * g.W * g.H, g.W, g.W, g.H, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->fb.depth + (size_t)slots[i] * g.Wd * g.Hd, depth + (size_t)i * g.Wd * g.Hd, (size_t)g.Wd * g.Hd * 2,
-                          hipMemcpyDeviceToDevice, c->stream));
-  }
+  launch_ingest(c, n, gray, depth, c->d_fargs);  // level-0 copy (frame.cpp:47-50) + raw depth into the slots
   return enqueue_prepare(c, n, c->d_fargs, c->d_fargs + n);
 }
 
@@ -312,15 +330,7 @@ int rvo_prepare_frames(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* d
   if (n == 0) return RVO_OK;
   HIPCHK(hipSetDevice(c->device));
   const FrameGeom& g = c->g;
-  if (c->stage_frames < (size_t)n) {
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->d_gray_stage) (void)hipFree(c->d_gray_stage);
-    if (c->d_depth_stage) (void)hipFree(c->d_depth_stage);
-    c->d_gray_stage = nullptr; c->d_depth_stage = nullptr; c->stage_frames = 0;
-    HIPCHK(hipMalloc((void**)&c->d_gray_stage, (size_t)n * g.W * g.H));
-    HIPCHK(hipMalloc((void**)&c->d_depth_stage, (size_t)n * g.Wd * g.Hd * 2));
-    c->stage_frames = n;
-  }
+  { int rc0 = ensure_stage(c, n); if (rc0) return rc0; }
   HIPCHK(hipMemcpyAsync(c->d_gray_stage, gray, (size_t)n * g.W * g.H, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->d_depth_stage, depth, (size_t)n * g.Wd * g.Hd * 2, hipMemcpyHostToDevice, c->stream));
   int rc = rvo_prepare_frames_dev(c, n, c->d_gray_stage, c->d_depth_stage, thr, slots);

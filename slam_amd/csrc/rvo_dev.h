@@ -59,6 +59,7 @@ struct FrameBufs {
 struct PairBufs {
   int32_t* ref_slot;   // [pairs]
   int32_t* tgt_slot;   // [pairs]
+  int32_t* rot_slot;   // [pairs] "prev" frame of EstimateInitialRotation (vo.cpp:107-110); = ref_slot for FrameMatcher
   int32_t* active;     // [pairs] 0 = skip every stage for this pair
   double* init_pose;   // [pairs][12]
   double* q0;          // [pairs][4]
@@ -73,6 +74,8 @@ struct PairBufs {
   float2* m_uv;        // refined kp.u, kp.v
   double* m_rect;      // [pairs][mcap][2] refined rect_base_uv
   double* m_xyz;       // [pairs][mcap][3] refined xyz
+  double* m_rrect;     // [pairs][mcap][2] reference keypoint rect_base_uv (gathered copy)
+  double* m_rxyz;      // [pairs][mcap][3] reference keypoint xyz (gathered copy)
   int32_t* m_degree;   // [pairs][mcap]
   uint8_t* m_inlier;   // [pairs][mcap] indexed by id
   double* m_reproj;    // [pairs][mcap] indexed by id

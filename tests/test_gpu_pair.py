@@ -1,0 +1,144 @@
+"""GPU parity: FrameMatcher::Match / MotionEstimator::EstimateMotion on the HIP path vs the CPU oracle.
+
+Bit-exact: match lists (ref/target index, level, status), refined sub-pixel positions, rectified
+positions, refined XYZ, consistency degrees, the std::sort order and the inlier set.
+Tolerance (fp64 reductions are tree-ordered on the GPU, sequential in the oracle; sin/cos/atan2 come
+from different libms): pose 1e-9 here, far inside north_star's 1e-5 m / 1e-6 rad.
+"""
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-9
+
+
+def rot_angle(Ra, Rb):
+    c = (np.trace(Ra.T @ Rb) - 1) / 2
+    return float(np.arccos(np.clip(c, -1, 1)))
+
+
+def compare_pair(ctx, orc, pair, rg, ro, exact_dbl=True):
+    assert rg["status"] == ro["status"]
+    assert rg["num_matches"] == ro["num_matches"]
+    assert rg["num_inliers"] == ro["num_inliers"]
+    assert rg["num_reprojection_failures"] == ro["num_reprojection_failures"]
+    n = ro["num_matches"]
+    ig, dg = ctx.matches(pair, n)
+    io, do = orc.matches(n)
+    assert np.array_equal(ig, io), "match list / sort order / inlier set differ"
+    if exact_dbl:
+        assert np.array_equal(dg[:, :7], do[:, :7], equal_nan=True), "refined uv / rect / xyz differ"
+    np.testing.assert_allclose(dg[:, 7], do[:, 7], rtol=0, atol=1e-7)
+    assert np.abs(rg["pose"][:, 3] - ro["pose"][:, 3]).max() < POSE_TOL
+    assert rot_angle(rg["pose"][:, :3], ro["pose"][:, :3]) < 1e-7  # arccos near 1 has ~1e-8 resolution
+    assert np.abs(rg["pose"] - ro["pose"]).max() < POSE_TOL
+    if ro["status"] == 1:
+        np.testing.assert_allclose(rg["cov"], ro["cov"], rtol=1e-6, atol=1e-12)
+        assert abs(rg["mean_reprojection_error"] - ro["mean_reprojection_error"]) < 1e-9
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 5])
+def test_match_pair_640(scene, intr640, seed):
+    from oracle.pyoracle import Oracle, default_params as odef
+    from slam_amd.api import Context, default_params
+    ctx = Context(intr640, default_params(frame_matcher=True), max_frames=2, max_pairs=1)
+    orc = Oracle(intr640, odef(frame_matcher=True))
+    g0, d0, g1, d1, T = synth.make_pair(seed, intr640, scene)
+    ctx.prepare_frames(np.stack([g0, g1]), np.stack([d0, d1]), 20, [0, 1])
+    orc.prepare(0, g0, d0, 20)
+    orc.prepare(1, g1, d1, 20)
+    qg = ctx.initial_rotation([0], [1])[0]
+    qo = orc.initial_rotation(0, 1)
+    np.testing.assert_allclose(qg, qo, rtol=0, atol=1e-9)
+    rg = ctx.match_pairs([0], [1])[0]
+    ro = orc.match_pair(0, 1)
+    assert ro["status"] == 1 and ro["num_inliers"] > 100
+    compare_pair(ctx, orc, 0, rg, ro)
+    # and the estimate is right: ground truth within depth-quantisation noise
+    assert np.abs(rg["pose"] - T[:3]).max() < 2e-3
+    ctx.close()
+
+
+def test_match_batch_with_given_init(scene, intr640):
+    """Several pairs in one call, EstimateMotion with an explicit initial estimate (the VO call form, vo.cpp:118-122)."""
+    from oracle.pyoracle import Oracle
+    from slam_amd.api import Context
+    n = 6
+    ctx = Context(intr640, max_frames=2 * n, max_pairs=n)
+    orc = Oracle(intr640)
+    grays, depths, inits = [], [], []
+    for s in range(n):
+        g0, d0, g1, d1, T = synth.make_pair(20 + s, intr640, scene, invalid_frac=0.15 if s % 2 else 0.0,
+                                            max_t=0.05, max_rot_deg=1.5)
+        grays += [g0, g1]
+        depths += [d0, d1]
+        noisy = T.copy()
+        noisy[:3, 3] += 0.01 * (s - 2)
+        inits.append(noisy[:3])
+        orc.prepare(2 * s, g0, d0, 15)
+        orc.prepare(2 * s + 1, g1, d1, 15)
+    ctx.prepare_frames(np.stack(grays), np.stack(depths), 15, list(range(2 * n)))
+    refs, tgts = list(range(0, 2 * n, 2)), list(range(1, 2 * n, 2))
+    res = ctx.match_pairs(refs, tgts, np.stack(inits))
+    for s in range(n):
+        ro = orc.estimate_motion(2 * s, 2 * s + 1, inits[s])
+        compare_pair(ctx, orc, s, res[s], ro)
+    ctx.close()
+
+
+def test_adversarial_low_texture_invalid_depth(intr640):
+    """BASELINE config 5: ~5 grey levels of contrast and 30 % invalid depth: sparse matches, refinement failures,
+    NaN-clamp quirk, INSUFFICIENT_INLIERS."""
+    from oracle.pyoracle import Oracle, default_params as odef
+    from slam_amd.api import Context, default_params
+    sc = synth.PlaneScene(contrast=0.12)
+    statuses = set()
+    ctx = Context(intr640, default_params(frame_matcher=True), max_frames=2, max_pairs=1)
+    orc = Oracle(intr640, odef(frame_matcher=True))
+    for seed in range(4):
+        g0, d0, g1, d1, _ = synth.make_pair(40 + seed, intr640, sc, invalid_frac=0.3)
+        thr = 5
+        ctx.prepare_frames(np.stack([g0, g1]), np.stack([d0, d1]), thr, [0, 1])
+        orc.prepare(0, g0, d0, thr)
+        orc.prepare(1, g1, d1, thr)
+        rg = ctx.match_pairs([0], [1])[0]
+        ro = orc.match_pair(0, 1)
+        statuses.add(ro["status"])
+        compare_pair(ctx, orc, 0, rg, ro)
+    ctx.close()
+    print("statuses seen:", statuses)
+
+
+def test_no_features_pair(intr640):
+    """Constant images: zero keypoints, zero matches -> INSUFFICIENT_INLIERS, pose = initial estimate."""
+    from slam_amd.api import Context
+    ctx = Context(intr640, max_frames=2, max_pairs=1)
+    g = np.full((2, 480, 640), 90, np.uint8)
+    d = np.full((2, 480, 640), 2000, np.uint16)
+    ctx.prepare_frames(g, d, 20, [0, 1])
+    r = ctx.match_pairs([0], [1])[0]
+    assert r["status"] == 2 and r["num_matches"] == 0 and r["num_inliers"] == 0
+    assert np.allclose(r["pose"], np.eye(4)[:3])
+    ctx.close()
+
+
+def test_large_frames_config4(scene):
+    """BASELINE config 4: 1280x960, 4 pyramid levels (large consistency matrix / clique stress)."""
+    from oracle.pyoracle import Oracle, default_params as odef
+    from slam_amd.api import Context, default_params
+    intr = synth.default_intrinsics(1280, 960)
+    kw = dict(num_pyramid_levels=4)
+    ctx = Context(intr, default_params(frame_matcher=True, **kw), max_frames=2, max_pairs=1)
+    orc = Oracle(intr, odef(frame_matcher=True, **kw))
+    g0, d0, g1, d1, T = synth.make_pair(7, intr, scene)
+    ctx.prepare_frames(np.stack([g0, g1]), np.stack([d0, d1]), 20, [0, 1])
+    orc.prepare(0, g0, d0, 20)
+    orc.prepare(1, g1, d1, 20)
+    rg = ctx.match_pairs([0], [1])[0]
+    ro = orc.match_pair(0, 1)
+    assert ro["num_matches"] > 1500
+    compare_pair(ctx, orc, 0, rg, ro)
+    ctx.close()
