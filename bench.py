@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Benchmark of the rgbdvo front-end on MI355X (BASELINE.json metric: frame-pairs/sec at 640x480).
+
+Workload (configs[1]): a batch of 256 independent synthetic 640x480 gray+depth frame pairs per GPU, 3-level
+pyramid, default feature grid.  One step = Frame::PrepareFrame on all 512 frames + FrameMatcher::Match on the
+256 pairs (initial rotation, matching, refinement, clique, Gauss-Newton), inputs resident in HBM.
+N > 1: one process per GPU (torchrun), every rank runs its own 256 pairs (weak scaling, no collective in the
+timed loop); the per-pair poses are gathered once at the end over RCCL (all_gather) and timed separately.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def _render_pair(args):
+    seed, = args
+    from slam_amd import synth
+    intr = synth.default_intrinsics(640, 480)
+    g0, d0, g1, d1, T = synth.make_pair(seed, intr, synth.PlaneScene())
+    return g0, d0, g1, d1, T[:3]
+
+
+def make_batch(n_pairs: int, seed0: int):
+    from concurrent.futures import ProcessPoolExecutor
+    from slam_amd import synth
+    synth.make_texture()  # build once before forking
+    workers = int(os.environ.get("RVO_BENCH_WORKERS", "8"))
+    with ProcessPoolExecutor(max_workers=workers) as ex:
+        out = list(ex.map(_render_pair, [(seed0 + i,) for i in range(n_pairs)], chunksize=4))
+    gray = np.empty((2 * n_pairs, 480, 640), np.uint8)
+    depth = np.empty((2 * n_pairs, 480, 640), np.uint16)
+    for i, (g0, d0, g1, d1, _) in enumerate(out):
+        gray[2 * i], gray[2 * i + 1] = g0, g1
+        depth[2 * i], depth[2 * i + 1] = d0, d1
+    return gray, depth, np.stack([o[4] for o in out])
+
+
+def algorithmic_bytes(geom: dict, stats: dict) -> dict:
+    """Algorithmic HBM bytes per LAUNCH of each kernel kind (definitions: DESIGN.md section 5)."""
+    W, H, L = geom["W"], geom["H"], geom["levels"]
+    nf, npair = stats["n_frames"], stats["n_pairs"]
+    lv = [(W >> l) * (H >> l) for l in range(L)]
+    K, N = stats["mean_kp_per_frame"], stats["mean_matches"]
+    B = {}
+    B["ingest"] = nf * (2 * W * H + 4 * W * H)
+    B["pyr_down"] = nf * sum(lv[l - 1] + lv[l] for l in range(1, L)) / max(1, L - 1)
+    B["fast_grid"] = nf * (sum(lv) + geom["total_buckets"] * (geom["max_per"] * 4 + 8))
+    B["build_keypoints"] = nf * (geom["total_buckets"] * (geom["max_per"] * 4 + 8) + K * (80 + 36 + 8 + 4 + 81))
+    B["init_rotation"] = npair * 2 * lv[L - 1]
+    B["match"] = npair * (2 * K * 80 + 2 * K * 32 + N * 8)
+    B["refine"] = npair * N * (2 * 100 + 120)
+    B["consistency"] = npair * (N * N / 8 + N * 48)
+    B["clique"] = npair * (N * N / 8 + N * 12)
+    B["gauss_newton"] = npair * N * 88
+    return B
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=256, help="independent frame pairs per GPU per step")
+    ap.add_argument("--cpu-pairs", type=int, default=192, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_pairs = a.pairs
+
+    # synthetic inputs first (forks workers; nothing has touched the GPU yet)
+    gray, depth, T_gt = make_batch(n_pairs, seed0=100000 * rank)
+
+    import torch
+    import torch.distributed as dist
+    from slam_amd import synth
+    from slam_amd.api import Context, default_params
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    d_gray = torch.from_numpy(gray).to(dev)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
+
+    intr = synth.default_intrinsics(640, 480)
+    ctx = Context(intr, default_params(frame_matcher=True), max_frames=2 * n_pairs, max_pairs=n_pairs, device=local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    slots = np.arange(2 * n_pairs, dtype=np.int32)
+    refs, tgts = slots[0::2].copy(), slots[1::2].copy()
+    thr = ctx.params.fast_init_threshold
+
+    def step():
+        ctx.prepare_frames_dev(d_gray.data_ptr(), d_depth.data_ptr(), thr, slots)
+        ctx.match_pairs_async(refs, tgts)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    ctx.profile_enable(True)  # HIP events around every launch, on the stream the kernels run on
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # results + final trajectory gather (RCCL all_gather of the per-pair 3x4 poses and status)
+    res = ctx.pair_results(n_pairs)
+    poses = torch.tensor(np.stack([r["pose"].reshape(12) for r in res]), dtype=torch.float64, device=dev)
+    gather_ms = None
+    if world > 1:
+        out = torch.empty((world * n_pairs, 12), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(out, poses)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    ok = sum(r["status"] == 1 for r in res)
+    err = max(np.abs(r["pose"] - T_gt[i]).max() for i, r in enumerate(res) if r["status"] == 1) if ok else float("nan")
+    kp = [sum(ctx.level_info(s, l)["num_keypoints"] for l in range(3)) for s in range(0, 2 * n_pairs, 37)]
+    stats = dict(n_frames=2 * n_pairs, n_pairs=n_pairs, mean_kp_per_frame=float(np.mean(kp)),
+                 mean_matches=float(np.mean([r["num_matches"] for r in res])),
+                 mean_inliers=float(np.mean([r["num_inliers"] for r in res])))
+
+    if rank == 0:
+        total_pairs = world * n_pairs * a.steps
+        value = total_pairs / dt
+        geom = dict(W=640, H=480, levels=3, total_buckets=64, max_per=25)
+        B = algorithmic_bytes(geom, stats)
+        dom = max(prof, key=lambda k: prof[k]["total_ms"]) if prof else None
+        roof = None
+        if dom and dom in B:
+            avg_s = prof[dom]["total_ms"] / prof[dom]["calls"] * 1e-3
+            ach = B[dom] / avg_s
+            roof = dict(bound="hbm", kernel=dom, achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                        frac=ach / HBM_PEAK, traffic=None, avg_launch_ms=avg_s * 1e3,
+                        algorithmic_bytes_per_launch=B[dom])
+        kernels = {k: dict(avg_ms=v["total_ms"] / v["calls"], calls=v["calls"],
+                           GBps=(B[k] / (v["total_ms"] / v["calls"] * 1e-3) / 1e9) if k in B else None)
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+        # whole-path roofline with SURVEY 8(d)'s per-pair figure evaluated at the measured K and N
+        K, N = stats["mean_kp_per_frame"], stats["mean_matches"]
+        b_frame = 640 * 480 + 2 * (320 * 240 + 160 * 120) + 128 * K + 4 * K
+        b_pair = 2 * b_frame + 160 * K + N * N / 4
+        cpu = None
+        if world == 1 and not a.no_cpu:
+            from oracle.pyoracle import Oracle, default_params as odef
+            orc = Oracle(intr, odef(frame_matcher=True))
+            m = min(a.cpu_pairs, n_pairs)
+            c0 = time.perf_counter()
+            same = 0
+            for i in range(m):
+                orc.prepare(0, gray[2 * i], depth[2 * i], thr)
+                orc.prepare(1, gray[2 * i + 1], depth[2 * i + 1], thr)
+                ro = orc.match_pair(0, 1)
+                same += (ro["num_matches"] == res[i]["num_matches"] and ro["num_inliers"] == res[i]["num_inliers"]
+                         and ro["status"] == res[i]["status"])
+            cdt = time.perf_counter() - c0
+            cpu = dict(value=m / cdt, unit="frame-pairs/s", cores=1, kind="port",
+                       sample=f"first {m} of the same {n_pairs} pairs, oracle/librvo_oracle.so single thread; "
+                              f"{same}/{m} pairs have identical match/inlier counts and status to the GPU result")
+        line = dict(metric="frame-pairs/sec (whole node) at 640x480", value=value, unit="frame-pairs/s",
+                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8/int32/f64", data="synthetic",
+                    config=dict(workload=f"configs[1]: {n_pairs} independent synthetic 640x480 gray+depth frame pairs "
+                                         f"per GPU, 3-level pyramid, default feature grid (80x80x25), device-resident inputs",
+                                pairs_per_gpu=n_pairs, parallelism=f"dp{world} (independent pairs, no collective in loop)"),
+                    roofline=roof,
+                    roofline_path=dict(bytes_per_pair=b_pair, frac=value / world * b_pair / HBM_PEAK,
+                                       note="SURVEY 8(d) B_pair at the measured K and N, per GPU"),
+                    cpu_baseline=cpu, kernels=kernels, stats=stats,
+                    check=dict(pairs_success=ok, max_abs_pose_err_vs_truth=float(err)),
+                    gather_ms=gather_ms)
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,12 @@ struct rvo_ctx {
   int32_t* d_pargs = nullptr;
   double* d_pinit = nullptr;
   int lds_rot = 0, lds_match = 0, lds_clique = 0;
+  // pinned ring for small host->device argument arrays (slot lists, thresholds, initial poses)
+  static const int kRing = 8;
+  uint8_t* h_ring = nullptr;
+  size_t ring_bytes = 0;
+  hipEvent_t ring_ev[kRing] = {};
+  int ring_pos = 0;
   // profiling
   bool prof = false;
   std::vector<std::string> prof_names;
@@ -73,6 +79,23 @@ static int dalloc(rvo_ctx* c, T** p, size_t n) {
   if (e != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e); return RVO_E_NOMEM; }
   c->allocs.push_back(v);
   *p = (T*)v;
+  return 0;
+}
+
+// Stream-ordered H2D copy of a small argument array through pinned memory; never blocks on prior GPU work
+// (a pageable hipMemcpyAsync may) and never lets the host buffer be reused while a copy is pending.
+static int stage_args(rvo_ctx* c, void* dst_dev, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  if (bytes > c->ring_bytes) { g_err = "stage_args: argument array larger than the staging region"; return RVO_E_INVALID; }
+  const int r = c->ring_pos;
+  c->ring_pos = (r + 1) % rvo_ctx::kRing;
+  hipError_t e = hipEventSynchronize(c->ring_ev[r]);
+  if (e != hipSuccess) { g_err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); return RVO_E_HIP; }
+  uint8_t* h = c->h_ring + (size_t)r * c->ring_bytes;
+  memcpy(h, src, bytes);
+  e = hipMemcpyAsync(dst_dev, h, bytes, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipEventRecord(c->ring_ev[r], c->stream);
+  if (e != hipSuccess) { g_err = std::string("stage_args: ") + hipGetErrorString(e); return RVO_E_HIP; }
   return 0;
 }
 
@@ -210,6 +233,9 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   if (fl.total > 150 * 1024) { g_err = "grid cell too large for LDS"; delete c; return RVO_E_UNSUPPORTED; }
 
   int rc = 0;
+  c->ring_bytes = std::max<size_t>(4096, (size_t)std::max(max_frames, max_pairs) * 12 * 8);
+  HIPCHK(hipHostMalloc((void**)&c->h_ring, c->ring_bytes * rvo_ctx::kRing, hipHostMallocDefault));
+  for (int i = 0; i < rvo_ctx::kRing; i++) HIPCHK(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   FrameBufs& fb = c->fb;
@@ -256,6 +282,8 @@ void rvo_destroy(rvo_ctx* c) {
   prof_drain(c);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
+  if (c->h_ring) (void)hipHostFree(c->h_ring);
+  for (int i = 0; i < rvo_ctx::kRing; i++) if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
   if (c->d_gray_stage) (void)hipFree(c->d_gray_stage);
   if (c->d_depth_stage) (void)hipFree(c->d_depth_stage);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -320,7 +348,7 @@ int rvo_prepare_frames_dev(rvo_ctx* c, int n, const uint8_t* gray, const uint16_
   std::vector<int32_t> args(2 * (size_t)n);
   memcpy(args.data(), slots, n * 4);
   memcpy(args.data() + n, thr, n * 4);
-  HIPCHK(hipMemcpyAsync(c->d_fargs, args.data(), args.size() * 4, hipMemcpyHostToDevice, c->stream));
+  { int rc0 = stage_args(c, c->d_fargs, args.data(), args.size() * 4); if (rc0) return rc0; }
   launch_ingest(c, n, gray, depth, c->d_fargs);  // level-0 copy (frame.cpp:47-50) + raw depth into the slots
   return enqueue_prepare(c, n, c->d_fargs, c->d_fargs + n);
 }
