@@ -135,16 +135,17 @@ def main():
 
     # results + final trajectory gather (RCCL all_gather of the per-pair 3x4 poses and status)
     res = ctx.pair_results(n_pairs)
-    poses = torch.tensor(np.stack([r["pose"].reshape(12) for r in res]), dtype=torch.float64, device=dev)
     gather_ms = None
     if world > 1:
-        out = torch.empty((world * n_pairs, 12), dtype=torch.float64, device=dev)
+        from slam_amd.dist import gather_trajectories
+        local = np.stack([np.concatenate([r["pose"].reshape(12), [r["status"], r["num_inliers"]]]) for r in res])
         torch.cuda.synchronize()
         dist.barrier()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(out, poses)
+        allp = gather_trajectories(local, dev)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        assert allp.shape == (world * n_pairs, 14)
 
     ok = sum(r["status"] == 1 for r in res)
     err = max(np.abs(r["pose"] - T_gt[i]).max() for i, r in enumerate(res) if r["status"] == 1) if ok else float("nan")

@@ -152,9 +152,10 @@ int rvo_get_grid_keypoints(rvo_ctx* ctx, int slot, int level, float* uvs /* [n][
 int rvo_get_keypoints(rvo_ctx* ctx, int slot, int level, float* uvs /* [n][3] */, double* rect /* [n][2] */,
                       double* xyz /* [n][3] */);
 int rvo_get_descriptors(rvo_ctx* ctx, int slot, int level, uint8_t* out /* [n][80] */);
-/* matches of pair `pair` from the last rvo_match_pairs, in the reference's post-sort order:
+/* matches of pair `pair` from the last rvo_match_pairs, in the reference's post-sort order (at most `cap` rows
+ * are written; returns the number written, or a negative error):
  * ints[n][7] = ref_idx,tgt_idx,level,status,inlier,id,degree; dbl[n][8] = refined u,v, rect u,v, xyz, reproj error */
-int rvo_get_matches(rvo_ctx* ctx, int pair, int32_t* ints, double* dbl);
+int rvo_get_matches(rvo_ctx* ctx, int pair, int cap, int32_t* ints, double* dbl);
 int rvo_get_lut(rvo_ctx* ctx, float* xmap, float* ymap);
 
 /* ---- measurement support ---- */

@@ -159,7 +159,7 @@ class Oracle:
     def matches(self, n):
         ints = np.zeros((n, 7), np.int32)
         dbl = np.zeros((n, 8), np.float64)
-        self.L.orc_get_matches(self.h, _p(ints), _p(dbl))
+        self.L.orc_get_matches(self.h, C.c_int(n), _p(ints), _p(dbl))
         return ints, dbl
 
 

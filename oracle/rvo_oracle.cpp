@@ -1482,9 +1482,9 @@ void orc_match_pair(void* cv, int ref_slot, int tgt_slot, PairResult* out) {
 
 // dump of the last EstimateMotion's match array (post-sort order)
 // ints[n][7] = ref_idx,tgt_idx,level,status,inlier,id,degree ; dbl[n][8] = refined u,v, rect u,v, xyz, reproj
-void orc_get_matches(void* cv, int32_t* ints, double* dbl) {
+void orc_get_matches(void* cv, int cap, int32_t* ints, double* dbl) {
   Ctx* c = (Ctx*)cv;
-  for (size_t i = 0; i < c->est.matches.size(); i++) {
+  for (size_t i = 0; i < c->est.matches.size() && (int)i < cap; i++) {
     const FeatureMatch& m = c->est.matches[i];
     int32_t* a = ints + 7 * i;
     a[0] = m.ref_idx; a[1] = m.target_idx; a[2] = m.level; a[3] = m.status; a[4] = m.inlier; a[5] = m.id; a[6] = m.compatibility_degree;

@@ -87,7 +87,7 @@ def load():
     L.rvo_get_grid_keypoints.argtypes = [vp, ip, ip, vp]
     L.rvo_get_keypoints.argtypes = [vp, ip, ip, vp, vp, vp]
     L.rvo_get_descriptors.argtypes = [vp, ip, ip, vp]
-    L.rvo_get_matches.argtypes = [vp, ip, vp, vp]
+    L.rvo_get_matches.argtypes = [vp, ip, ip, vp, vp]
     L.rvo_get_lut.argtypes = [vp, vp, vp]
     L.rvo_profile_enable.argtypes = [vp, ip]
     L.rvo_profile_read.argtypes = [vp, ip, vp, vp, vp]

@@ -177,7 +177,9 @@ class Context:
     def matches(self, pair, n):
         ints = np.zeros((n, 7), np.int32)
         dbl = np.zeros((n, 8), np.float64)
-        self._chk(self.L.rvo_get_matches(self.h, pair, _ptr(ints), _ptr(dbl)))
+        rc = self.L.rvo_get_matches(self.h, pair, n, _ptr(ints), _ptr(dbl))
+        if rc < 0:
+            self._chk(rc)
         return ints, dbl
 
     def lut(self):

@@ -1,0 +1,50 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the sharding + trajectory gather used by bench.py."""
+import os
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from slam_amd.dist import gather_trajectories, shard_range
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_streams, T = 7, 5  # ragged: 4 + 3
+    mine = shard_range(n_streams, rank, world)
+    local = np.stack([np.arange(T * 12, dtype=np.float64).reshape(T, 12) + 1000 * s for s in mine])
+    allp = gather_trajectories(local)
+    q.put((rank, list(mine), allp))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    want = np.stack([np.arange(60, dtype=np.float64).reshape(5, 12) + 1000 * s for s in range(7)])
+    shards = sorted(got)
+    assert shards[0][1] + shards[1][1] == list(range(7))
+    for _, _, allp in got:
+        assert np.array_equal(allp, want)
+
+
+def test_shard_range_covers_everything():
+    sys.path.insert(0, ROOT)
+    from slam_amd.dist import shard_range
+    for n in (0, 1, 7, 4096):
+        for w in (1, 2, 3, 8):
+            idx = [i for r in range(w) for i in shard_range(n, r, w)]
+            assert idx == list(range(n))
