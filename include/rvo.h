@@ -140,6 +140,9 @@ int rvo_streams_reset(rvo_ctx* ctx, int n_streams);
 int rvo_stream_step(rvo_ctx* ctx, int n_streams, const uint8_t* gray, const uint16_t* depth, rvo_stream_result* out);
 int rvo_stream_step_dev(rvo_ctx* ctx, int n_streams, const uint8_t* gray_dev, const uint16_t* depth_dev);
 int rvo_get_stream_results(rvo_ctx* ctx, int n_streams, rvo_stream_result* out);
+/* Frame slots stream `stream` currently holds: out[3] = reference, previous, current frame
+ * (ref_frame_/prev_frame_/curr_frame_ of rgbdvo/vo.hpp:67-69) -- lets the facade resolve match indices to keypoints. */
+int rvo_get_stream_slots(rvo_ctx* ctx, int stream, int32_t* out);
 /* Device pointer to the stream-result array (for a device-side trajectory buffer / RCCL gather). */
 int rvo_stream_results_dev(rvo_ctx* ctx, void** dev_ptr);
 

@@ -49,6 +49,7 @@ SYMBOLS = [
     "rvo_set_stream", "rvo_sync", "rvo_prepare_frames", "rvo_prepare_frames_dev", "rvo_match_pairs",
     "rvo_match_pairs_async", "rvo_get_pair_results", "rvo_initial_rotation", "rvo_streams_reset",
     "rvo_stream_step", "rvo_stream_step_dev", "rvo_get_stream_results", "rvo_stream_results_dev",
+    "rvo_get_stream_slots",
     "rvo_get_level_info", "rvo_get_level_image", "rvo_get_grid_keypoints", "rvo_get_keypoints",
     "rvo_get_descriptors", "rvo_get_matches", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_read",
 ]
@@ -82,6 +83,7 @@ def load():
     L.rvo_stream_step_dev.argtypes = [vp, ip, vp, vp]
     L.rvo_get_stream_results.argtypes = [vp, ip, vp]
     L.rvo_stream_results_dev.argtypes = [vp, C.POINTER(vp)]
+    L.rvo_get_stream_slots.argtypes = [vp, ip, vp]
     L.rvo_get_level_info.argtypes = [vp, ip, ip, vp]
     L.rvo_get_level_image.argtypes = [vp, ip, ip, vp]
     L.rvo_get_grid_keypoints.argtypes = [vp, ip, ip, vp]

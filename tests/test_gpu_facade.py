@@ -1,0 +1,54 @@
+"""GPU: the C++ facade (include/rgbdvo/: RGBDVO, FrameMatcher, MotionEstimator read surface) driven the way
+hand_held_demo.cpp / pose_graph.cpp drive the reference, against the Python mirror of the same C ABI."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_facade_matches_python_mirror(scene, tmp_path):
+    from slam_amd.api import FrameMatcher, RGBDVOStreams, default_params
+    exe = os.path.join(ROOT, "tests", "native", "facade_demo")
+    assert os.path.exists(exe), "run ./build.sh"
+    W, H, N = 320, 240, 7
+    intr = synth.default_intrinsics(W, H)
+    seq = list(synth.make_sequence(N, seed=9, intr=intr, scene=scene))
+    raw = tmp_path / "frames.raw"
+    with open(raw, "wb") as f:
+        for g, d, _ in seq:
+            f.write(g.tobytes())
+            f.write(d.tobytes())
+    out = subprocess.run([exe, str(raw), str(W), str(H), str(N), "100"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    vo_lines = [l.split() for l in out.stdout.splitlines() if l.startswith("VO")]
+    fm_lines = [l.split() for l in out.stdout.splitlines() if l.startswith("FM")]
+    assert len(vo_lines) == N
+
+    vo = RGBDVOStreams(intr, 1, params=default_params())  # warm-up 100, as in the reference
+    for _ in range(99):
+        r = vo.ProcessFrame(seq[0][0][None], seq[0][1][None])[0]
+        assert r["rc"] == 0
+    for i, (g, d, _) in enumerate(seq):
+        r = vo.ProcessFrame(g[None], d[None])[0]
+        l = vo_lines[i]
+        assert int(l[2]) == int(r["keyframe_changed"])
+        assert int(l[3]) == r["num_matches"] and int(l[4]) == r["num_inliers"]
+        assert int(l[5]) == r["num_inliers"]  # every inlier resolved to ref/target keypoints (the demo's drawing loop)
+        assert np.array_equal(np.array(l[6:18], float).reshape(3, 4), r["pose"])
+    T_gt = np.linalg.inv(seq[0][2]) @ seq[-1][2]
+    assert np.abs(np.array(vo_lines[-1][6:18], float).reshape(3, 4) - T_gt[:3]).max() < 5e-3
+
+    fm = FrameMatcher(intr)
+    fm.SetRefFrame(seq[0][0], seq[0][1])
+    for l in fm_lines:
+        i = int(l[1])
+        ok = fm.Match(seq[i][0], seq[i][1])
+        assert int(l[2]) == int(ok) and int(l[3]) == 6
+        assert np.array_equal(np.array(l[4:16], float).reshape(3, 4), fm.GetMotionEstimate()[:3])
+        assert float(l[16]) == fm.GetCov()[0, 0]
