@@ -161,6 +161,11 @@ int rvo_get_descriptors(rvo_ctx* ctx, int slot, int level, uint8_t* out /* [n][8
 int rvo_get_matches(rvo_ctx* ctx, int pair, int cap, int32_t* ints, double* dbl);
 int rvo_get_lut(rvo_ctx* ctx, float* xmap, float* ymap);
 
+/* Self-test hook (no counterpart in the reference): runs the wave-parallel replay of libstdc++'s std::sort
+ * (nth < 0) or std::nth_element(nth) that the kernels use (slam_amd/csrc/wave_stdalgo.h) on n <= 8192 host keys,
+ * comparator = descending by (key >> shift), shift = 16 or 22.  out receives the permuted keys. */
+int rvo_selftest_stdalgo(int device, const uint32_t* keys, int n, int shift, int nth, uint32_t* out);
+
 /* ---- measurement support ---- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
 int rvo_profile_enable(rvo_ctx* ctx, int on);

@@ -1496,6 +1496,18 @@ void orc_get_matches(void* cv, int cap, int32_t* ints, double* dbl) {
   }
 }
 
+// The real libstdc++ algorithms on (key, payload) records with a key-only comparator (descending), as used at
+// pyramid.cpp:42-45 and motion_estimate.cpp:526; `keys[i] >> shift` is the key.  nth < 0: std::sort.
+void orc_std_select_or_sort(uint32_t* keys, int n, int shift, int nth) {
+  struct Rec { int key; uint32_t full; double pad[3]; };
+  std::vector<Rec> v(n);
+  for (int i = 0; i < n; i++) { v[i].key = (int)(keys[i] >> shift); v[i].full = keys[i]; }
+  auto cmp = [](const Rec& a, const Rec& b) { return a.key > b.key; };
+  if (nth < 0) std::sort(v.begin(), v.end(), cmp);
+  else std::nth_element(v.begin(), v.begin() + nth, v.end(), cmp);
+  for (int i = 0; i < n; i++) keys[i] = v[i].full;
+}
+
 // ---- streaming VO
 void* orc_vo_create(void* cv, int base_slot) { return new VO((Ctx*)cv, base_slot); }
 void orc_vo_destroy(void* v) { delete (VO*)v; }

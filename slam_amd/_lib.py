@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librgbdvo_hip.so")
+LIB_PATH = os.environ.get("RVO_LIB", os.path.join(_HERE, "librgbdvo_hip.so"))
 
 
 class Intrinsics(C.Structure):
@@ -52,6 +52,7 @@ SYMBOLS = [
     "rvo_get_stream_slots",
     "rvo_get_level_info", "rvo_get_level_image", "rvo_get_grid_keypoints", "rvo_get_keypoints",
     "rvo_get_descriptors", "rvo_get_matches", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_read",
+    "rvo_selftest_stdalgo",
 ]
 
 _LIB = None
@@ -93,6 +94,7 @@ def load():
     L.rvo_get_lut.argtypes = [vp, vp, vp]
     L.rvo_profile_enable.argtypes = [vp, ip]
     L.rvo_profile_read.argtypes = [vp, ip, vp, vp, vp]
+    L.rvo_selftest_stdalgo.argtypes = [ip, vp, ip, ip, ip, vp]
     L.rvo_default_vo_params.argtypes = [C.POINTER(Params)]
     L.rvo_default_fm_params.argtypes = [C.POINTER(Params)]
     _LIB = L

@@ -7,6 +7,7 @@
 #pragma once
 #include "rvo_dev.h"
 #include "stdalgo.h"
+#include "wave_stdalgo.h"
 
 // ------------------------------------------------------------------ helpers
 __device__ inline int wave_sum(int v) {
@@ -152,21 +153,25 @@ __device__ inline bool has9(uint32_t m) {
 // Segment test of fast9Detect (feature.cpp:3033-5953; equivalence with the generated tree is checked
 // exhaustively by oracle/check_fast_tree.py) and fast9CornerScore (feature.cpp:67-2995): the binary
 // search returns the largest b for which the test passes = A-1, A = max over the 16 nine-arcs of the
-// arc's min |difference| with a consistent sign.  Returns 0 (no corner at threshold b) or score+1 = A.
-__device__ inline int fast9_score_plus1(const uint8_t* t, int pitch, int b) {
+// arc's min |difference| with a consistent sign.
+__device__ inline void fast9_ring_diffs(const uint8_t* t, int pitch, int* d) {
   const int p = t[0];
-  int d[16];
   d[0] = t[3 * pitch] - p;       d[1] = t[3 * pitch + 1] - p;   d[2] = t[2 * pitch + 2] - p;   d[3] = t[pitch + 3] - p;
   d[4] = t[3] - p;               d[5] = t[-pitch + 3] - p;      d[6] = t[-2 * pitch + 2] - p;  d[7] = t[-3 * pitch + 1] - p;
   d[8] = t[-3 * pitch] - p;      d[9] = t[-3 * pitch - 1] - p;  d[10] = t[-2 * pitch - 2] - p; d[11] = t[-pitch - 3] - p;
   d[12] = t[-3] - p;             d[13] = t[pitch - 3] - p;      d[14] = t[2 * pitch - 2] - p;  d[15] = t[3 * pitch - 1] - p;
+}
+__device__ inline bool fast9_is_corner(const int* d, int b) {
   uint32_t br = 0, dk = 0;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     br |= (uint32_t)(d[i] > b) << i;
     dk |= (uint32_t)(d[i] < -b) << i;
   }
-  if (!(has9(br) || has9(dk))) return 0;
+  return has9(br) || has9(dk);
+}
+// A = score + 1 (only meaningful for corners: A > b)
+__device__ inline int fast9_A(const int* d) {
   int lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
@@ -181,6 +186,18 @@ __device__ inline int fast9_score_plus1(const uint8_t* t, int pitch, int b) {
     best_hi = min(best_hi, hi9);
   }
   return max(best_lo, -best_hi);
+}
+
+// append `val` for the lanes with pass == true to an LDS queue (order irrelevant); wave-aggregated counter bump
+__device__ inline void lds_queue_push(bool pass, uint16_t val, uint16_t* q, int* count) {
+  const unsigned long long m = __ballot(pass);
+  if (m) {
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (pass) q[base + __popcll(m & ((1ull << lane) - 1ull))] = val;
+  }
 }
 
 struct FastLds {  // byte offsets into dynamic LDS, computed on the host (all multiples of 4)
@@ -219,71 +236,161 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   const uint8_t* __restrict__ img = fb.img + (size_t)slot * g.img_bytes + G.img_off;
   const int TP = L.tile_pitch, SP = L.score_pitch;
 
-  // ---- stage cell + 4 px halo
+  // ---- stage cell + 4 px halo (index walkers avoid per-element integer division)
   const int trows = ch + 8, tdw = TP / 4;
   const int gx0 = cx0 - 4, gy0 = cy0 - 4;
   const bool aligned = (gx0 & 3) == 0;
-  for (int i = tid; i < trows * tdw; i += 256) {
-    const int r = i / tdw, c4 = i % tdw;
-    const int gy = gy0 + r, gx = gx0 + 4 * c4;
-    uint32_t v = 0;
-    if (gy >= 0 && gy < G.h) {
-      const uint8_t* row = img + (size_t)gy * G.stride;
-      if (aligned && gx >= 0 && gx + 3 < G.stride) {
-        v = *reinterpret_cast<const uint32_t*>(row + gx);
-      } else {
-        for (int k = 0; k < 4; k++)
-          if (gx + k >= 0 && gx + k < G.stride) v |= (uint32_t)row[gx + k] << (8 * k);
+  {
+    const int q = 256 / tdw, rr = 256 % tdw;
+    int r = tid / tdw, c4 = tid % tdw;
+    while (r < trows) {
+      const int gy = gy0 + r, gx = gx0 + 4 * c4;
+      uint32_t v = 0;
+      if (gy >= 0 && gy < G.h) {
+        const uint8_t* row = img + (size_t)gy * G.stride;
+        if (aligned && gx >= 0 && gx + 3 < G.stride) {
+          v = *reinterpret_cast<const uint32_t*>(row + gx);
+        } else {
+          for (int k = 0; k < 4; k++)
+            if (gx + k >= 0 && gx + k < G.stride) v |= (uint32_t)row[gx + k] << (8 * k);
+        }
       }
+      *reinterpret_cast<uint32_t*>(s_tile + r * TP + 4 * c4) = v;
+      c4 += rr; r += q;
+      if (c4 >= tdw) { c4 -= tdw; r++; }
     }
-    *reinterpret_cast<uint32_t*>(s_tile + r * TP + 4 * c4) = v;
   }
-  __syncthreads();
-
-  // ---- FAST score for the cell + 1 px halo (0 = not a corner, else score+1)
+  // ---- FAST, phase A: cheap necessary test on the 4 compass ring pixels for every pixel of the cell + 1 px halo.
+  // A 9-arc of the 16-ring contains at least one pixel of each antipodal pair, so a corner needs
+  // (p0|p8) & (p4|p12) all brighter than p+b, or all darker than p-b.  Survivors are queued in LDS as (sy<<8|sx).
+  // Thread t owns pixels t, t+256, ... (<= 64 of them): pass bits are collected in a register mask first (independent
+  // LDS reads, no per-iteration atomics), then each wave reserves queue space with ONE atomicAdd.
   const int sw = cw + 2, sh = ch + 2;
-  for (int i = tid; i < sw * sh; i += 256) {
-    const int sy = i / sw, sx = i % sw;           // score-tile coords; cell pixel = (sx-1, sy-1)
-    const int gx = cx0 + sx - 1, gy = cy0 + sy - 1;
-    int s = 0;
-    if (gx >= 3 && gx <= G.w - 4 && gy >= 3 && gy <= G.h - 4)   // fast9Detect loop bounds, feature.cpp:3042-3043
-      s = fast9_score_plus1(s_tile + (sy + 3) * TP + (sx + 3), TP, b);
-    s_score[sy * SP + sx] = (uint8_t)s;
+  const int npix = sw * sh;
+  uint16_t* s_cand = reinterpret_cast<uint16_t*>(s_list);  // aliases the survivor list (used after later barriers)
+  uint16_t* s_corner = s_cand + (npix + 1) / 2;             // second half: queue of true corners
+  int* s_ncand = s_misc + 8;
+  int* s_ncorner = s_misc + 9;
+  uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_misc + 16);  // NMS survivor bitmap, one bit per cell pixel (raster)
+  const int P = cw * ch;
+  const int nwords = (P + 31) >> 5;
+  if (tid == 0) { *s_ncand = 0; *s_ncorner = 0; }
+  for (int w = tid; w < nwords; w += 256) s_bits[w] = 0;
+  __syncthreads();
+  const int lane = tid & 63;
+  {
+    const int q = 256 / sw, rr = 256 % sw;
+    const int sy0 = tid / sw, sx0 = tid % sw;   // score-tile coords; cell pixel = (sx-1, sy-1)
+    unsigned long long mask = 0;
+    int sy = sy0, sx = sx0;
+    for (int k = 0; sy < sh; k++) {
+      const int gx = cx0 + sx - 1, gy = cy0 + sy - 1;
+      s_score[sy * SP + sx] = 0;
+      if (gx >= 3 && gx <= G.w - 4 && gy >= 3 && gy <= G.h - 4) {  // fast9Detect loop bounds, feature.cpp:3042-3043
+        const uint8_t* t = s_tile + (sy + 3) * TP + (sx + 3);
+        const int p = t[0];
+        const int d0 = t[3 * TP] - p, d4 = t[3] - p, d8 = t[-3 * TP] - p, d12 = t[-3] - p;
+        const bool br = ((d0 > b) | (d8 > b)) & ((d4 > b) | (d12 > b));
+        const bool dk = ((d0 < -b) | (d8 < -b)) & ((d4 < -b) | (d12 < -b));
+        mask |= (unsigned long long)(br | dk) << k;
+      }
+      sx += rr; sy += q;
+      if (sx >= sw) { sx -= sw; sy++; }
+    }
+    // wave-level reservation
+    const int mine = __popcll(mask);
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
+    const int wtot = __shfl(inc, 63, 64);
+    int base = 0;
+    if (lane == 0 && wtot) base = atomicAdd(s_ncand, wtot);
+    base = __shfl(base, 0, 64) + inc - mine;
+    sy = sy0; sx = sx0;
+    for (int k = 0; mask >> k; k++) {
+      if ((mask >> k) & 1ull) s_cand[base++] = (uint16_t)((sy << 8) | sx);
+      sx += rr; sy += q;
+      if (sx >= sw) { sx -= sw; sy++; }
+    }
   }
   __syncthreads();
+  // ---- phase B: full segment test on the queued pixels; phase C: score for the true corners.  Both run with
+  // all lanes busy.  If more than half of the pixels were queued (dense noise) the two queues do not fit and
+  // the score is computed directly in phase B.
+  const int ncand = *s_ncand;
+  const bool two_queues = ncand <= npix / 2;
+  for (int c0 = 0; c0 < ncand; c0 += 256) {
+    const int c = c0 + tid;
+    bool corner = false;
+    uint16_t v = 0;
+    if (c < ncand) {
+      v = s_cand[c];
+      const int sy = v >> 8, sx = v & 255;
+      int d[16];
+      fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3), TP, d);
+      corner = fast9_is_corner(d, b);
+      if (corner && !two_queues) s_score[sy * SP + sx] = (uint8_t)fast9_A(d);
+    }
+    if (two_queues) lds_queue_push(corner, v, s_corner, s_ncorner);
+  }
+  __syncthreads();
+  const int nlist = two_queues ? *s_ncorner : ncand;
+  const uint16_t* s_qlist = two_queues ? s_corner : s_cand;
+  if (two_queues) {
+    for (int c = tid; c < nlist; c += 256) {
+      const uint16_t v = s_qlist[c];
+      const int sy = v >> 8, sx = v & 255;
+      int d[16];
+      fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3), TP, d);
+      s_score[sy * SP + sx] = (uint8_t)fast9_A(d);
+    }
+    __syncthreads();
+  }
 
-  // ---- NMS + raster-ordered compaction
-  const int P = cw * ch;
-  const int per = (P + 255) / 256;
-  const int i0 = min(P, tid * per), i1 = min(P, i0 + per);
-  auto survives = [&](int idx) -> int {
-    const int y = idx / cw, x = idx % cw;
-    const uint8_t* c = s_score + (y + 1) * SP + (x + 1);
-    const int s = c[0];
-    if (s == 0) return 0;
-    if (c[-1] >= s || c[1] >= s) return 0;
-    if (c[-SP - 1] >= s || c[-SP] >= s || c[-SP + 1] >= s) return 0;
-    if (c[SP - 1] >= s || c[SP] >= s || c[SP + 1] >= s) return 0;
-    return s;
-  };
-  int cnt = 0;
-  for (int i = i0; i < i1; i++) cnt += survives(i) != 0;
-  int total;
-  int pos = block_excl_scan_256(cnt, s_misc, &total);
-  for (int i = i0; i < i1; i++) {
-    const int s = survives(i);
-    if (s) {
-      if (pos < L.list_cap) s_list[pos] = kp_pack(cx0 + i % cw, cy0 + i / cw, s - 1);
+  // ---- NMS (feature.cpp:5960-6056: a corner survives iff no 8-neighbour corner has score >= its own) on the
+  // queued pixels only; survivors set one bit of a raster-ordered bitmap of the cell.
+  for (int c = tid; c < nlist; c += 256) {
+    const uint16_t v = s_qlist[c];
+    const int sy = v >> 8, sx = v & 255;
+    if (sx < 1 || sx > cw || sy < 1 || sy > ch) continue;  // halo pixels belong to neighbouring buckets
+    const uint8_t* cc = s_score + sy * SP + sx;
+    const int sc = cc[0];
+    if (sc == 0) continue;
+    const bool sup = cc[-1] >= sc || cc[1] >= sc || cc[-SP - 1] >= sc || cc[-SP] >= sc || cc[-SP + 1] >= sc ||
+                     cc[SP - 1] >= sc || cc[SP] >= sc || cc[SP + 1] >= sc;
+    if (!sup) {
+      const int idx = (sy - 1) * cw + (sx - 1);
+      atomicOr(&s_bits[idx >> 5], 1u << (idx & 31));
+    }
+  }
+  __syncthreads();
+  // ---- raster-ordered compaction of the bitmap (the order the reference pushes keypoints into the bucket)
+  int total = 0, base_run = 0;
+  for (int w0 = 0; w0 < nwords; w0 += 256) {
+    const int w = w0 + tid;
+    uint32_t word = w < nwords ? s_bits[w] : 0u;
+    int tot;
+    int pos = base_run + block_excl_scan_256(__popc(word), s_misc, &tot);
+    while (word) {
+      const int bit = __ffs(word) - 1;
+      word &= word - 1;
+      const int idx = (w << 5) + bit;
+      const int y = idx / cw, x = idx - y * cw;
+      if (pos < L.list_cap) s_list[pos] = kp_pack(cx0 + x, cy0 + y, s_score[(y + 1) * SP + (x + 1)] - 1);
       pos++;
     }
+    base_run += tot;
   }
+  total = base_run;
   __syncthreads();
 
   // ---- GridKeyPointFilter::Filter for this bucket (pyramid.cpp:38-50)
   const int n = min(total, L.list_cap);
   const int maxp = g.max_per;
-  if (n > maxp && tid == 0)
-    stdalgo::nth_element(s_list, maxp, n, [](uint32_t l, uint32_t r) { return kp_s(l) > kp_s(r); });
+  if (n > maxp && tid < 64) {  // wave 0 replays std::nth_element; the image tile is dead by now and serves as scratch
+    uint16_t* li = reinterpret_cast<uint16_t*>(s_tile);
+    wavealgo::wave_nth_element<22>(s_list, maxp, n, li, li + L.list_cap);
+  }
   __syncthreads();
   const int keep = min(n, maxp);
   uint32_t* out = fb.bk_kp + ((size_t)slot * g.total_buckets + gb) * maxp;

@@ -12,6 +12,7 @@
 #include "kernels_frame.h"
 #include "rvo_dev.h"
 #include "stdalgo.h"
+#include "wave_stdalgo.h"
 
 #define NONE_KEY 0xFFFFFFFFu
 
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
 }
 
 // ------------------------------------------------------------------ sort + greedy clique
-// grid (n_pairs), 64 threads (one wave); dynamic LDS = mcap*4 + cwords*4 + 512.
+// grid (n_pairs), 64 threads (one wave); dynamic LDS = mcap*16 + cwords*4 + 1024.
 __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
   extern __shared__ __align__(16) uint8_t lds[];
   const int pair = blockIdx.x, lane = threadIdx.x;
@@ -591,6 +592,11 @@ __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
   uint32_t* keys = reinterpret_cast<uint32_t*>(lds);
   uint32_t* acc = keys + pb.mcap;
   int* stack = reinterpret_cast<int*>(acc + pb.cwords);
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(stack + 128);
+  uint16_t* li = reinterpret_cast<uint16_t*>(tmp + pb.mcap);
+  uint16_t* ri = li + pb.mcap;
+  uint16_t* ls = ri + pb.mcap;
+  uint16_t* le = ls + pb.mcap;
   const int N = pb.n_matches[pair];
   const size_t mb = (size_t)pair * pb.mcap;
   rvo_pair_result* res = pb.result + pair;
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
   for (int w = lane; w < nw; w += 64) acc[w] = 0;
   __syncthreads();
   // std::sort(_matches, _matches+N, consistencyCompare): unstable, replayed exactly
-  if (lane == 0) stdalgo::sort(keys, N, [](uint32_t a, uint32_t b) { return (a >> 16) > (b >> 16); }, stack);
+  wavealgo::wave_sort<16>(keys, N, li, ri, ls, le, tmp, stack);
   __syncthreads();
   for (int i = lane; i < N; i += 64) pb.order[mb + i] = keys[i];
 
@@ -1132,4 +1138,27 @@ __global__ void k_stream_post2(StreamState* st, int n, StreamParams sp, PairBufs
   for (int k = 0; k < 36; k++) o.cov[k] = S.cov[k];
   o.fast_threshold = S.fast_thr;
   o.keyframe_changed = S.ref_changed_flag;
+}
+
+// ------------------------------------------------------------------ self-test of wave_stdalgo.h (one wave)
+__global__ __launch_bounds__(64) void k_selftest_stdalgo(uint32_t* keys, int n, int shift, int nth) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  uint32_t* a = reinterpret_cast<uint32_t*>(lds);
+  uint32_t* tmp = a + n;
+  uint16_t* li = reinterpret_cast<uint16_t*>(tmp + n);
+  uint16_t* ri = li + n;
+  uint16_t* ls = ri + n;
+  uint16_t* le = ls + n;
+  int* stack = reinterpret_cast<int*>(le + n + (n & 1));
+  for (int i = threadIdx.x; i < n; i += 64) a[i] = keys[i];
+  __syncthreads();
+  if (nth < 0) {
+    if (shift == 16) wavealgo::wave_sort<16>(a, n, li, ri, ls, le, tmp, stack);
+    else wavealgo::wave_sort<22>(a, n, li, ri, ls, le, tmp, stack);
+  } else {
+    if (shift == 16) wavealgo::wave_nth_element<16>(a, nth, n, li, ri);
+    else wavealgo::wave_nth_element<22>(a, nth, n, li, ri);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 64) keys[i] = a[i];
 }

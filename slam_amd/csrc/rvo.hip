@@ -228,9 +228,10 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   fl.off_score = round_up(fl.tile_pitch * (g.gh + 8), 16);
   fl.off_list = fl.off_score + round_up(fl.score_pitch * (g.gh + 2), 16);
   fl.list_cap = ((g.gw + 1) / 2) * ((g.gh + 1) / 2) + 1;
-  fl.off_misc = fl.off_list + round_up(fl.list_cap * 4, 16);
-  fl.total = fl.off_misc + 64;
-  if (fl.total > 150 * 1024) { g_err = "grid cell too large for LDS"; delete c; return RVO_E_UNSUPPORTED; }
+  // the same region first holds the phase-A candidate queue: u16 per pixel of the (gw+2)x(gh+2) score region
+  fl.off_misc = fl.off_list + round_up(std::max(fl.list_cap * 4, (g.gw + 2) * (g.gh + 2) * 2 + 4), 16);
+  fl.total = fl.off_misc + 64 + round_up((g.gw * g.gh + 31) / 32 * 4, 16);
+  if (fl.total > 150 * 1024 || g.gw + 2 > 255 || g.gh + 2 > 255 || (g.gw + 2) * (g.gh + 2) > 64 * 256) { g_err = "grid cell too large for LDS"; delete c; return RVO_E_UNSUPPORTED; }
 
   int rc = 0;
   c->ring_bytes = std::max<size_t>(4096, (size_t)std::max(max_frames, max_pairs) * 12 * 8);
