@@ -40,6 +40,30 @@ __device__ inline int block_excl_scan_256(int v, int* s_wave, int* total) {
   return base + inc - v;
 }
 
+// same for any block size of NW waves (s_wave: NW ints)
+template <int NW>
+__device__ inline int block_excl_scan(int v, int* s_wave, int* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int n = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += n;
+  }
+  __syncthreads();
+  if (lane == 63) s_wave[wid] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    int t = s_wave[w];
+    if (w < wid) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
 // ------------------------------------------------------------------ ingest
 // Level-0 copy (frame.cpp:47-50) and raw depth copy into the frame slots; grid (blocks, n_frames).
 // VEC: 16-byte path (W % 16 == 0, Wd*Hd % 8 == 0 and 16-byte aligned sources).

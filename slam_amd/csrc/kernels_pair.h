@@ -289,8 +289,33 @@ __global__ __launch_bounds__(256) void k_init_rotation(FrameBufs fb, FrameGeom g
 }
 
 // ------------------------------------------------------------------ matching
-// grid (levels, n_pairs), 256 threads; dynamic LDS = kp_cap(level 0) * 16 bytes + 16.
-__global__ __launch_bounds__(256) void k_match(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, EstParams ep) {
+#define MATCH_THREADS 1024
+#define MATCH_WAVES (MATCH_THREADS / 64)
+#define MATCH_QCAP 256  // per-wave candidate queue entries; flushed when fewer than 64 slots are left
+
+// SAD of two 80-byte descriptors (feature.hpp:364-381), both 16-byte aligned
+__device__ inline uint32_t sad80(const uint8_t* a, const uint8_t* b) {
+  const uint4* a4 = reinterpret_cast<const uint4*>(a);
+  const uint4* b4 = reinterpret_cast<const uint4*>(b);
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const uint4 x = a4[k], y = b4[k];
+    s = __builtin_amdgcn_sad_u8(x.x, y.x, s);
+    s = __builtin_amdgcn_sad_u8(x.y, y.y, s);
+    s = __builtin_amdgcn_sad_u8(x.z, y.z, s);
+    s = __builtin_amdgcn_sad_u8(x.w, y.w, s);
+  }
+  return s;
+}
+
+// grid (levels, n_pairs), 1024 threads; dynamic LDS = kp_cap(level 0) * 16 + MATCH_WAVES * MATCH_QCAP * 4 + 128.
+// Phase 1 (dense, fp64): every wave walks its reference keypoints against all target keypoints 64 at a time and
+// queues the (ref,target) pairs inside the search window.  Phase 2 (whenever the wave's queue fills): one lane
+// per queued pair computes the SAD and folds it into the per-ref and per-target bests with LDS atomicMin on
+// (score<<16 | index) keys -- the lexicographic minimum is exactly the reference's "strictly smaller score wins,
+// first in iteration order on ties" (feature.cpp:6301-6308).
+__global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, EstParams ep) {
   extern __shared__ __align__(16) uint8_t lds[];
   const int lvl = blockIdx.x, pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (!pb.active[pair]) return;
@@ -299,7 +324,8 @@ __global__ __launch_bounds__(256) void k_match(FrameBufs fb, FrameGeom g, PairBu
   float2* s_tuv = reinterpret_cast<float2*>(lds);
   uint32_t* s_bt = reinterpret_cast<uint32_t*>(lds + (size_t)cap * 8);
   uint32_t* s_br = s_bt + cap;
-  int* s_wave = reinterpret_cast<int*>(s_br + cap);
+  uint32_t* s_q = s_br + cap + (size_t)wid * MATCH_QCAP;
+  int* s_wave = reinterpret_cast<int*>(s_br + cap + (size_t)MATCH_WAVES * MATCH_QCAP);
   const int rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
   const int nr = fb.kp_cnt[rs * RVO_MAX_LEVELS + lvl], nt = fb.kp_cnt[ts * RVO_MAX_LEVELS + lvl];
   const size_t rbase = (size_t)rs * g.kp_total + G.kp_off, tbase = (size_t)ts * g.kp_total + G.kp_off;
@@ -311,57 +337,54 @@ __global__ __launch_bounds__(256) void k_match(FrameBufs fb, FrameGeom g, PairBu
   double RP[12];
   proj_matrix(cam.fx, cam.fy, cam.cx, cam.cy, r2t, RP);
 
-  for (int i = tid; i < nt; i += 256) { s_tuv[i] = fb.kp_rect[tbase + i]; s_bt[i] = NONE_KEY; }
-  for (int i = tid; i < nr; i += 256) s_br[i] = NONE_KEY;
+  for (int i = tid; i < nt; i += MATCH_THREADS) { s_tuv[i] = fb.kp_rect[tbase + i]; s_bt[i] = NONE_KEY; }
+  for (int i = tid; i < nr; i += MATCH_THREADS) s_br[i] = NONE_KEY;
   __syncthreads();
 
   const double win = ep.feature_search_window;
   const double win2 = win * win, lo2 = win2 * (1.0 - 1e-9), hi2 = win2 * (1.0 + 1e-9);
-  for (int r0 = wid; r0 < nr; r0 += 4) {
+  int qn = 0;  // wave-uniform queue fill
+  auto flush = [&]() {
+    for (int e = lane; e < qn; e += 64) {
+      const uint32_t rt = s_q[e];
+      const uint32_t r = rt >> 16, t = rt & 0xFFFF;
+      const uint32_t s = sad80(fb.kp_desc + (rbase + r) * RVO_DESC_LEN, fb.kp_desc + (tbase + t) * RVO_DESC_LEN);
+      atomicMin(&s_br[r], (s << 16) | t);
+      atomicMin(&s_bt[t], (s << 16) | r);
+    }
+    qn = 0;
+  };
+  for (int r0 = wid; r0 < nr; r0 += MATCH_WAVES) {
     const int r = __builtin_amdgcn_readfirstlane(r0);
     const double* X = fb.kp_xyz + (rbase + r) * 3;
     const double u = dot4(RP, X[0], X[1], X[2], 1.0), v = dot4(RP + 4, X[0], X[1], X[2], 1.0), w = dot4(RP + 8, X[0], X[1], X[2], 1.0);
     const double inv = 1.0 / w;  // Eigen 3.2 `v /= s` multiplies by the reciprocal
     const double pu = u * inv, pv = v * inv;
-    const uint4* rd4 = reinterpret_cast<const uint4*>(fb.kp_desc + (rbase + r) * RVO_DESC_LEN);
-    uint4 rd[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) rd[k] = rd4[k];
-    uint32_t best = NONE_KEY;
     for (int t0 = 0; t0 < nt; t0 += 64) {
       const int t = t0 + lane;
+      bool cand = false;
       if (t < nt) {
         const float2 uv = s_tuv[t];
         const double ex = (double)uv.x - pu, ey = (double)uv.y - pv;
         const double d2 = ex * ex + ey * ey;
         // err.norm() < window (motion_estimate.cpp:335); sqrt only in the 1e-9 band around the threshold
-        bool cand = d2 < lo2 ? true : (d2 > hi2 ? false : sqrt(d2) < win);
-        if (cand) {
-          const uint4* td4 = reinterpret_cast<const uint4*>(fb.kp_desc + (tbase + t) * RVO_DESC_LEN);
-          uint32_t s = 0;
-#pragma unroll
-          for (int k = 0; k < 5; k++) {
-            const uint4 td = td4[k];
-            s = __builtin_amdgcn_sad_u8(rd[k].x, td.x, s);
-            s = __builtin_amdgcn_sad_u8(rd[k].y, td.y, s);
-            s = __builtin_amdgcn_sad_u8(rd[k].z, td.z, s);
-            s = __builtin_amdgcn_sad_u8(rd[k].w, td.w, s);
-          }
-          // strict '<' with ascending iteration = lexicographic min of (score, index), feature.cpp:6301-6308
-          best = min(best, (s << 16) | (uint32_t)t);
-          atomicMin(&s_bt[t], (s << 16) | (uint32_t)r);
-        }
+        cand = d2 < lo2 ? true : (d2 > hi2 ? false : sqrt(d2) < win);
+      }
+      const unsigned long long m = __ballot(cand);
+      if (m) {
+        if (cand) s_q[qn + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)r << 16) | (uint32_t)t;
+        qn += __popcll(m);
+        if (qn > MATCH_QCAP - 64) flush();
       }
     }
-    best = wave_min_u(best);
-    if (lane == 0) s_br[r] = best;
   }
+  flush();
   __syncthreads();
   // mutual best matches in ref-index order, feature.cpp:6313-6333
   int32_t* lm_ref = pb.lm_ref + (size_t)pair * g.kp_total + G.kp_off;
   int32_t* lm_tgt = pb.lm_tgt + (size_t)pair * g.kp_total + G.kp_off;
   int base = 0;
-  for (int c0 = 0; c0 < nr; c0 += 256) {
+  for (int c0 = 0; c0 < nr; c0 += MATCH_THREADS) {
     const int r = c0 + tid;
     int flag = 0, t = 0;
     if (r < nr) {
@@ -372,7 +395,7 @@ __global__ __launch_bounds__(256) void k_match(FrameBufs fb, FrameGeom g, PairBu
       }
     }
     int total;
-    const int pos = base + block_excl_scan_256(flag, s_wave, &total);
+    const int pos = base + block_excl_scan<MATCH_WAVES>(flag, s_wave, &total);
     if (flag) { lm_ref[pos] = r; lm_tgt[pos] = t; }
     base += total;
   }
