@@ -429,16 +429,27 @@ __device__ inline int norm_px(int v, int mean) {  // Descriptor::Normalized, fea
   return v;
 }
 
-// grid (ceil(kp_total/128), n_pairs), 128 threads: one lane per match.
-__global__ __launch_bounds__(128) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
+// sum over the 16 lanes of a match group
+__device__ inline int group16_sum(int v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+  return v;
+}
+
+#define REFINE_GROUP 16
+#define REFINE_TAPS (RVO_DESC_LEN / REFINE_GROUP)  // 5 taps per lane
+// grid (ceil(kp_total/16), n_pairs), 256 threads: 16 lanes per match, 5 descriptor taps per lane; all sums are exact
+// int32, so the lane split does not change any value.  Branches below are uniform within a 16-lane group.
+__global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
   const int pair = blockIdx.y;
   if (!pb.active[pair]) return;
-  const int i = blockIdx.x * 128 + threadIdx.x;
+  const int gl = threadIdx.x & (REFINE_GROUP - 1);
+  const int i = blockIdx.x * (256 / REFINE_GROUP) + (threadIdx.x / REFINE_GROUP);
   int off[RVO_MAX_LEVELS + 1];
   off[0] = 0;
   for (int l = 0; l < g.levels; l++) off[l + 1] = off[l] + pb.lm_cnt[pair * RVO_MAX_LEVELS + l];
   const int N = off[g.levels];
-  if (i == 0) pb.n_matches[pair] = N;
+  if (i == 0 && gl == 0) pb.n_matches[pair] = N;
   if (i >= N) return;
   int lvl = 0;
   for (int l = 1; l < g.levels; l++) if (i >= off[l]) lvl = l;
@@ -454,32 +465,55 @@ __global__ __launch_bounds__(128) void k_refine(FrameBufs fb, FrameGeom g, PairB
   const int S = G.stride;
 
   // ---- refineFeatureMatch, motion_estimate.cpp:757-900 (descriptors recomputed per pass instead of stored)
+  int toff[REFINE_TAPS];
+#pragma unroll
+  for (int m = 0; m < REFINE_TAPS; m++) toff[m] = desc_off(gl + REFINE_GROUP * m, S);
+  auto interp = [&](const Wts& w, int o) -> int {
+    const int k = w.base + o;
+    const float f = ((w.wa * (float)tg[k] + w.wb * (float)tg[k + 1]) + w.wc * (float)tg[k + S]) + w.wd * (float)tg[k + S + 1];
+    return (int)f;
+  };
   const int rbase = kp_y(rkp) * S + kp_x(rkp);
   const float tu = (float)kp_x(tkp), tv = (float)kp_y(tkp);
   float tx = tu, ty = tv;
   Wts wt = make_wts(tx, ty, S);
+  int rraw[REFINE_TAPS], rdx[REFINE_TAPS], rdy[REFINE_TAPS], traw[REFINE_TAPS];
   int rsum = 0, tsum = 0;
-  for (int k = 0; k < RVO_DESC_LEN; k++) { rsum += rg[rbase + desc_off(k, S)]; tsum += interp_raw(tg, S, wt, k); }
-  const int rmean = rsum / RVO_DESC_LEN;
-  int tmean = tsum / RVO_DESC_LEN;
+#pragma unroll
+  for (int m = 0; m < REFINE_TAPS; m++) {
+    const int kr = rbase + toff[m];
+    rraw[m] = rg[kr];
+    rdx[m] = rg[kr + 1] - rraw[m];
+    rdy[m] = rg[kr + S] - rraw[m];
+    traw[m] = interp(wt, toff[m]);
+    rsum += rraw[m];
+    tsum += traw[m];
+  }
+  const int rmean = group16_sum(rsum) / RVO_DESC_LEN;
+  int tmean = group16_sum(tsum) / RVO_DESC_LEN;
+  int rn[REFINE_TAPS];
   int final_sse = 0;
-  for (int k = 0; k < RVO_DESC_LEN; k++) {
-    const int e = norm_px(interp_raw(tg, S, wt, k), tmean) - norm_px(rg[rbase + desc_off(k, S)], rmean);
+#pragma unroll
+  for (int m = 0; m < REFINE_TAPS; m++) {
+    rn[m] = norm_px(rraw[m], rmean);
+    const int e = norm_px(traw[m], tmean) - rn[m];
     final_sse += e * e;
   }
+  final_sse = group16_sum(final_sse);
   const int min_xy = RVO_WIN, max_x = G.w - RVO_WIN - 2, max_y = G.h - RVO_WIN - 2;  // pyramid.cpp:123-126
   for (int it = 0; it < 6; it++) {
     const int tc = ((int)ty) * S + (int)tx;
     int S00 = 0, S01 = 0, S11 = 0, gxs = 0, gys = 0;
-    for (int k = 0; k < RVO_DESC_LEN; k++) {
-      const int o = desc_off(k, S);
-      const int kr = rbase + o, kt = tc + o;
-      const int r0 = rg[kr], t0 = tg[kt];
-      const int mx = (rg[kr + 1] - r0) + (tg[kt + 1] - t0);
-      const int my = (rg[kr + S] - r0) + (tg[kt + S] - t0);
-      const int e = norm_px(interp_raw(tg, S, wt, k), tmean) - norm_px(r0, rmean);
+#pragma unroll
+    for (int m = 0; m < REFINE_TAPS; m++) {
+      const int kt = tc + toff[m];
+      const int t0 = tg[kt];
+      const int mx = rdx[m] + (tg[kt + 1] - t0);
+      const int my = rdy[m] + (tg[kt + S] - t0);
+      const int e = norm_px(traw[m], tmean) - rn[m];
       S00 += mx * mx; S01 += mx * my; S11 += my * my; gxs += mx * e; gys += my * e;
     }
+    S00 = group16_sum(S00); S01 = group16_sum(S01); S11 = group16_sum(S11); gxs = group16_sum(gxs); gys = group16_sum(gys);
     const double s00 = S00, s01 = S01, s11 = S11;
     const double det = s00 * s11 - s01 * s01;
     if (det <= 1e-9) break;
@@ -490,17 +524,26 @@ __global__ __launch_bounds__(128) void k_refine(FrameBufs fb, FrameGeom g, PairB
     const float ntx = (float)((double)tx + dxs), nty = (float)((double)ty + dys);
     if (!(ntx >= (float)min_xy && ntx <= (float)max_x && nty >= (float)min_xy && nty <= (float)max_y)) break;
     const Wts wn = make_wts(ntx, nty, S);
+    int nraw[REFINE_TAPS];
     int nsum = 0;
-    for (int k = 0; k < RVO_DESC_LEN; k++) nsum += interp_raw(tg, S, wn, k);
-    const int nmean = nsum / RVO_DESC_LEN;
+#pragma unroll
+    for (int m = 0; m < REFINE_TAPS; m++) { nraw[m] = interp(wn, toff[m]); nsum += nraw[m]; }
+    const int nmean = group16_sum(nsum) / RVO_DESC_LEN;
     int sse = 0;
-    for (int k = 0; k < RVO_DESC_LEN; k++) {
-      const int e = norm_px(interp_raw(tg, S, wn, k), nmean) - norm_px(rg[rbase + desc_off(k, S)], rmean);
+#pragma unroll
+    for (int m = 0; m < REFINE_TAPS; m++) {
+      const int e = norm_px(nraw[m], nmean) - rn[m];
       sse += e * e;
     }
-    if (sse < final_sse) { tx = ntx; ty = nty; final_sse = sse; wt = wn; tmean = nmean; } else break;
+    sse = group16_sum(sse);
+    if (sse < final_sse) {
+      tx = ntx; ty = nty; final_sse = sse; tmean = nmean;
+#pragma unroll
+      for (int m = 0; m < REFINE_TAPS; m++) traw[m] = nraw[m];
+    } else break;
     if (fabs(dxs) < 0.1 && fabs(dys) < 0.1) break;
   }
+  if (gl != 0) return;  // one lane finishes the record
 
   // ---- gating + refined record, motion_estimate.cpp:360-376
   const double ddx = (double)tu - (double)tx, ddy = (double)tv - (double)ty;
