@@ -611,40 +611,63 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
 }
 
 // ------------------------------------------------------------------ consistency matrix
-// grid (ceil(mcap/256), n_pairs), 256 threads: lane = row i; columns visited uniformly per wave.
+#define CONS_TILE 1024
+// grid (ceil(mcap/256), n_pairs), 256 threads: lane = row i; columns are staged through LDS in tiles of 1024 matches
+// as fp32 (broadcast reads).  |‖ref_j-ref_i‖ - ‖tgt_j-tgt_i‖| < thr (motion_estimate.cpp:505-507) is first evaluated
+// in fp32 (absolute error < 2e-5 m for coordinates up to 65 m) and repeated in fp64 -- Eigen 3.2's
+// sqrt(x*x + (y*y + z*z)) -- only inside a 1e-4 m band around the threshold, so every decision equals the fp64 one.
 __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) {
+  __shared__ float s_c[CONS_TILE * 6];
   const int pair = blockIdx.y;
   if (!pb.active[pair]) return;
   const int N = pb.n_matches[pair];
-  const int wave_row0 = blockIdx.x * 256 + (threadIdx.x & ~63);
-  if (wave_row0 >= N) return;
+  if (blockIdx.x * 256 >= N) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool live = i < N;
   const size_t mb = (size_t)pair * pb.mcap;
   const int ii = live ? i : N - 1;
   const double r1x = pb.m_rxyz[(mb + ii) * 3], r1y = pb.m_rxyz[(mb + ii) * 3 + 1], r1z = pb.m_rxyz[(mb + ii) * 3 + 2];
   const double t1x = pb.m_xyz[(mb + ii) * 3], t1y = pb.m_xyz[(mb + ii) * 3 + 1], t1z = pb.m_xyz[(mb + ii) * 3 + 2];
+  const float fr1x = (float)r1x, fr1y = (float)r1y, fr1z = (float)r1z, ft1x = (float)t1x, ft1y = (float)t1y, ft1z = (float)t1z;
   const double thr = ep.clique_inlier_threshold;
+  const float thr_lo = (float)(thr - 1e-4), thr_hi = (float)(thr + 1e-4);
   uint32_t* row = pb.cbits + (mb + ii) * pb.cwords;
   int degree = 0;
-  const int nw = (N + 31) >> 5;
-  for (int wj = 0; wj < nw; wj++) {
-    uint32_t word = 0;
-    const int jend = min(32, N - wj * 32);
-    for (int b = 0; b < jend; b++) {
-      const int j = wj * 32 + b;  // wave-uniform: scalar loads
-      const double* rj = pb.m_rxyz + (mb + j) * 3;
-      const double* tj = pb.m_xyz + (mb + j) * 3;
-      // (ref_xyz_2 - ref_xyz_1).norm() with Eigen 3.2's x*x + (y*y + z*z); motion_estimate.cpp:505-507
-      double dx = rj[0] - r1x, dy = rj[1] - r1y, dz = rj[2] - r1z;
-      const double rd = sqrt(dx * dx + (dy * dy + dz * dz));
-      dx = tj[0] - t1x; dy = tj[1] - t1y; dz = tj[2] - t1z;
-      const double td = sqrt(dx * dx + (dy * dy + dz * dz));
-      const bool c = (fabs(rd - td) < thr) && (j != i);
-      word |= (uint32_t)c << b;
+  for (int j0 = 0; j0 < N; j0 += CONS_TILE) {
+    const int nt = min(CONS_TILE, N - j0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < nt * 3; k += 256) {
+      s_c[(k / 3) * 6 + k % 3] = (float)pb.m_rxyz[(mb + j0) * 3 + k];
+      s_c[(k / 3) * 6 + 3 + k % 3] = (float)pb.m_xyz[(mb + j0) * 3 + k];
     }
-    degree += __popc(word);
-    if (live) row[wj] = word;
+    __syncthreads();
+    for (int w0 = 0; w0 < nt; w0 += 32) {
+      uint32_t word = 0;
+      const int jend = min(32, nt - w0);
+      for (int b = 0; b < jend; b++) {
+        const float* cj = s_c + (w0 + b) * 6;
+        float dx = cj[0] - fr1x, dy = cj[1] - fr1y, dz = cj[2] - fr1z;
+        const float rd = __builtin_sqrtf(dx * dx + (dy * dy + dz * dz));
+        dx = cj[3] - ft1x; dy = cj[4] - ft1y; dz = cj[5] - ft1z;
+        const float td = __builtin_sqrtf(dx * dx + (dy * dy + dz * dz));
+        const float df = fabsf(rd - td);
+        bool c = df < thr_lo;
+        if (!c && !(df > thr_hi)) {  // ambiguous band or NaN: exact fp64 evaluation
+          const int j = j0 + w0 + b;
+          const double* rj = pb.m_rxyz + (mb + j) * 3;
+          const double* tj = pb.m_xyz + (mb + j) * 3;
+          double ex = rj[0] - r1x, ey = rj[1] - r1y, ez = rj[2] - r1z;
+          const double rdd = sqrt(ex * ex + (ey * ey + ez * ez));
+          ex = tj[0] - t1x; ey = tj[1] - t1y; ez = tj[2] - t1z;
+          const double tdd = sqrt(ex * ex + (ey * ey + ez * ez));
+          c = fabs(rdd - tdd) < thr;
+        }
+        c = c && (j0 + w0 + b != i);
+        word |= (uint32_t)c << b;
+      }
+      degree += __popc(word);
+      if (live) row[(j0 + w0) >> 5] = word;
+    }
   }
   if (live) pb.m_degree[mb + i] = degree;
 }
