@@ -712,9 +712,11 @@ __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
     const int id = key & 0xFFFF, deg = (int)(key >> 16);
     const uint32_t* __restrict__ row = pb.cbits + (mb + id) * pb.cwords;
     bool ok = valid;
-    if (valid)
-      for (int w = 0; w < nw; w++)
-        if (acc[w] & ~row[w]) { ok = false; break; }
+    if (valid) {  // no early exit: the row words are independent loads, all in flight at once
+      uint32_t bad = 0;
+      for (int w = 0; w < nw; w++) bad |= acc[w] & ~row[w];
+      ok = bad == 0;
+    }
     unsigned long long cm = 0;
     const int kmax = min(64, N - c0);
     for (int k = 0; k < kmax; k++) {
@@ -803,31 +805,50 @@ __device__ inline void reverse_jac_mats(const double* prm, double fx, double px,
   for (int i = 0; i < 24; i++) { m.Ju[i] = Ju[i]; m.Jv[i] = Jv[i]; m.Jw[i] = Jw[i]; }
 }
 
-// 6x6 inverse by Gaussian elimination with partial pivoting (stand-in for Eigen's PartialPivLU inverse)
+// 6x6 inverse by Gaussian elimination with partial pivoting (stand-in for Eigen's PartialPivLU inverse).
+// Same operation order as oracle/rvo_oracle.cpp:inverse6; fully unrolled with static indices so the 6x12 tableau
+// stays in registers (a dynamically indexed row swap would send it to scratch memory).
 __device__ inline void inverse6(const double* A, double* inv) {
   double a[6][12];
+#pragma unroll
   for (int i = 0; i < 6; i++)
+#pragma unroll
     for (int j = 0; j < 6; j++) { a[i][j] = A[i * 6 + j]; a[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll
   for (int c = 0; c < 6; c++) {
     int piv = c;
     double best = fabs(a[c][c]);
+#pragma unroll
     for (int r = c + 1; r < 6; r++) if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
-    if (piv != c) for (int j = 0; j < 12; j++) { const double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+#pragma unroll
+    for (int r = c + 1; r < 6; r++)
+      if (r == piv) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) { const double t = a[c][j]; a[c][j] = a[r][j]; a[r][j] = t; }
+      }
     const double d = a[c][c];
+#pragma unroll
     for (int r = c + 1; r < 6; r++) {
       const double f = a[r][c] / d;
+#pragma unroll
       for (int j = c; j < 12; j++) a[r][j] -= f * a[c][j];
     }
   }
+#pragma unroll
   for (int c = 5; c >= 0; c--) {
     const double d = a[c][c];
+#pragma unroll
     for (int j = 6; j < 12; j++) {
       double s = a[c][j];
+#pragma unroll
       for (int k = c + 1; k < 6; k++) s -= a[c][k] * a[k][j];
       a[c][j] = s / d;
     }
   }
-  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) inv[i * 6 + j] = a[i][6 + j];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) inv[i * 6 + j] = a[i][6 + j];
 }
 
 struct GnShared {
