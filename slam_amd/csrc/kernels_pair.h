@@ -698,42 +698,93 @@ __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
   for (int w = lane; w < nw; w += 64) acc[w] = 0;
   __syncthreads();
   // std::sort(_matches, _matches+N, consistencyCompare): unstable, replayed exactly
+#ifndef ABL_NOSORT
   wavealgo::wave_sort<16>(keys, N, li, ri, ls, le, tmp, stack);
+#endif
   __syncthreads();
   for (int i = lane; i < N; i += 64) pb.order[mb + i] = keys[i];
 
-  // greedy clique, motion_estimate.cpp:529-569, 64 candidates per round
+  // greedy clique, motion_estimate.cpp:529-569, 64 candidates per round.  The 64 candidates' rows of the bit
+  // matrix are first copied into LDS with coalesced loads (the sort scratch is dead by now and is reused); lane k
+  // then owns row k: "consistent with every inlier so far" is a word-wise test against the accepted mask, and the
+  // 64x64 block of mutual consistency bits resolves the order dependence inside the round without memory traffic.
+  uint32_t* srow = tmp;                 // [64][pitch], aliases tmp/li/ri/ls/le (12*mcap bytes >= 64*pitch*4)
+  const int pitch = nw | 1;             // odd pitch: lane-strided reads are conflict-free
   int num_inl = 0;
   bool stop = false;
+#ifdef ABL_NOGREEDY
+  stop = true;
+#endif
+  // When a row fits one word per lane (N <= 2048) the next round's 64 rows are fetched into registers while the
+  // current round is resolved (the candidate order is already fixed by the sort), hiding the HBM/L2 round trip.
+  const bool pipelined = nw <= 64;
+  uint32_t pre[64];
+  auto fetch = [&](int c0) {
+    const int mm = c0 + lane;
+    const int idl = (mm < N) ? (int)(keys[mm] & 0xFFFF) : 0;
+#pragma unroll
+    for (int u = 0; u < 64; u++) {
+      const int idk = __shfl(idl, u, 64);
+      pre[u] = (lane < nw) ? pb.cbits[(mb + idk) * pb.cwords + lane] : 0u;
+    }
+  };
+  if (pipelined && !stop) fetch(0);
   for (int c0 = 0; c0 < N && !stop; c0 += 64) {
     const int m = c0 + lane;
     const bool valid = m < N;
     const uint32_t key = valid ? keys[m] : 0;
     const int id = key & 0xFFFF, deg = (int)(key >> 16);
-    const uint32_t* __restrict__ row = pb.cbits + (mb + id) * pb.cwords;
-    bool ok = valid;
-    if (valid) {  // no early exit: the row words are independent loads, all in flight at once
-      uint32_t bad = 0;
-      for (int w = 0; w < nw; w++) bad |= acc[w] & ~row[w];
-      ok = bad == 0;
-    }
-    unsigned long long cm = 0;
     const int kmax = min(64, N - c0);
-    for (int k = 0; k < kmax; k++) {
-      const int idk = __shfl(id, k, 64);
-      if (valid) cm |= (unsigned long long)((row[idk >> 5] >> (idk & 31)) & 1u) << k;
+    if (pipelined) {
+#pragma unroll
+      for (int u = 0; u < 64; u++)
+        if (lane < nw) srow[u * pitch + lane] = pre[u];
+      __syncthreads();
+      if (c0 + 64 < N) fetch(c0 + 64);
+    } else {
+      for (int w = lane; w < nw + ((-nw) & 63); w += 64) {  // wave-uniform trip count
+        for (int k0 = 0; k0 < 64; k0 += 16) {
+          uint32_t v[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) {  // 16 independent coalesced row loads in flight
+            const int idk = __shfl(id, k0 + u, 64);  // invalid lanes carry id 0: a harmless in-range row
+            v[u] = (w < nw) ? pb.cbits[(mb + idk) * pb.cwords + w] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < 16; u++)
+            if (w < nw) srow[(k0 + u) * pitch + w] = v[u];
+        }
+      }
+      __syncthreads();
     }
+    const uint32_t* row = srow + lane * pitch;
+    bool ok = valid;
+    unsigned long long cm = 0;
+    {
+      uint32_t bad = 0;
+#pragma unroll 8
+      for (int w = 0; w < nw; w++) bad |= acc[w] & ~row[w];
+      ok = valid && bad == 0;
+    }
+    // wave-uniform lane indices: v_readlane (a few cycles), not the LDS-crossbar shuffle
+#pragma unroll 8
     for (int k = 0; k < kmax; k++) {
-      const int degk = __shfl(deg, k, 64);
-      const int okk = __shfl((int)ok, k, 64);
+      const int idk = __builtin_amdgcn_readlane(id, k);
+      cm |= (unsigned long long)((row[idk >> 5] >> (idk & 31)) & 1u) << k;
+    }
+    const unsigned long long okm0 = __ballot(ok);  // lanes that are consistent with all earlier rounds
+    unsigned long long alive = okm0;                // updated as candidates of this round are accepted
+    for (int k = 0; k < kmax; k++) {
+      const int degk = __builtin_amdgcn_readlane(deg, k);
       if (degk < num_inl) { stop = true; break; }
-      if (okk) {
+      if ((alive >> k) & 1ull) {
         num_inl++;
+        // everyone inconsistent with candidate k drops out: bit k of lane j's cm == consistent(j, k)
+        alive &= __ballot((cm >> k) & 1ull) | (1ull << k);
         if (lane == k) {
           acc[id >> 5] |= 1u << (id & 31);
           pb.m_inlier[mb + id] = 1;
         }
-        ok = ok && ((cm >> k) & 1ull);
       }
     }
     __syncthreads();
