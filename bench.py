@@ -117,7 +117,8 @@ def main():
         if world > 1:
             dist.barrier()
 
-    ctx.profile_enable(True)  # HIP events around every launch, on the stream the kernels run on
+    if not os.environ.get("RVO_BENCH_NOPROF"):
+        ctx.profile_enable(True)  # HIP events around every launch, on the stream the kernels run on
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -156,7 +156,7 @@ __device__ inline void block_sum_d(double* v, double* s_red) {
 // mode 0: write q0 only; mode 1: also init_pose = Identity.rotate(q0) (fm.cpp:41-47).
 __global__ __launch_bounds__(256) void k_init_rotation(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, int mode) {
   extern __shared__ __align__(16) uint8_t lds[];
-  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x;
   if (!pb.active[pair]) return;
   const int irl = 4;
   const int pyr = min(g.levels - 1, irl);
@@ -317,7 +317,7 @@ __device__ inline uint32_t sad80(const uint8_t* a, const uint8_t* b) {
 // first in iteration order on ties" (feature.cpp:6301-6308).
 __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, EstParams ep) {
   extern __shared__ __align__(16) uint8_t lds[];
-  const int lvl = blockIdx.x, pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lvl = blockIdx.x, pair = blockIdx.y + pb.pair0, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (!pb.active[pair]) return;
   const LevelGeom G = g.lv[lvl];
   const int cap = g.lv[0].kp_cap;
@@ -441,7 +441,7 @@ __device__ inline int group16_sum(int v) {
 // grid (ceil(kp_total/16), n_pairs), 256 threads: 16 lanes per match, 5 descriptor taps per lane; all sums are exact
 // int32, so the lane split does not change any value.  Branches below are uniform within a 16-lane group.
 __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
-  const int pair = blockIdx.y;
+  const int pair = blockIdx.y + pb.pair0;
   if (!pb.active[pair]) return;
   const int gl = threadIdx.x & (REFINE_GROUP - 1);
   const int i = blockIdx.x * (256 / REFINE_GROUP) + (threadIdx.x / REFINE_GROUP);
@@ -617,8 +617,9 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
 // in fp32 (absolute error < 2e-5 m for coordinates up to 65 m) and repeated in fp64 -- Eigen 3.2's
 // sqrt(x*x + (y*y + z*z)) -- only inside a 1e-4 m band around the threshold, so every decision equals the fp64 one.
 __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) {
-  __shared__ float s_c[CONS_TILE * 6];
-  const int pair = blockIdx.y;
+  __shared__ float s_c[(CONS_TILE + 32) * 6];
+  const int pair = blockIdx.y + pb.pair0;
+  for (int k = threadIdx.x; k < (CONS_TILE + 32) * 6; k += 256) s_c[k] = 0.f;  // padding columns stay finite
   if (!pb.active[pair]) return;
   const int N = pb.n_matches[pair];
   if (blockIdx.x * 256 >= N) return;
@@ -642,29 +643,38 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
     }
     __syncthreads();
     for (int w0 = 0; w0 < nt; w0 += 32) {
-      uint32_t word = 0;
-      const int jend = min(32, nt - w0);
-      for (int b = 0; b < jend; b++) {
+      uint32_t word = 0, amb = 0;
+      // branch-free fp32 pass over 32 columns (columns past the tile end read stale-but-finite LDS and are masked)
+#pragma unroll 8
+      for (int b = 0; b < 32; b++) {
         const float* cj = s_c + (w0 + b) * 6;
         float dx = cj[0] - fr1x, dy = cj[1] - fr1y, dz = cj[2] - fr1z;
-        const float rd = __builtin_sqrtf(dx * dx + (dy * dy + dz * dz));
+        const float rd = __builtin_amdgcn_sqrtf(dx * dx + (dy * dy + dz * dz));  // raw v_sqrt_f32 (1 ulp) is enough for the prefilter
         dx = cj[3] - ft1x; dy = cj[4] - ft1y; dz = cj[5] - ft1z;
-        const float td = __builtin_sqrtf(dx * dx + (dy * dy + dz * dz));
+        const float td = __builtin_amdgcn_sqrtf(dx * dx + (dy * dy + dz * dz));
         const float df = fabsf(rd - td);
-        bool c = df < thr_lo;
-        if (!c && !(df > thr_hi)) {  // ambiguous band or NaN: exact fp64 evaluation
-          const int j = j0 + w0 + b;
-          const double* rj = pb.m_rxyz + (mb + j) * 3;
-          const double* tj = pb.m_xyz + (mb + j) * 3;
-          double ex = rj[0] - r1x, ey = rj[1] - r1y, ez = rj[2] - r1z;
-          const double rdd = sqrt(ex * ex + (ey * ey + ez * ez));
-          ex = tj[0] - t1x; ey = tj[1] - t1y; ez = tj[2] - t1z;
-          const double tdd = sqrt(ex * ex + (ey * ey + ez * ez));
-          c = fabs(rdd - tdd) < thr;
-        }
-        c = c && (j0 + w0 + b != i);
+        const bool c = df < thr_lo;
         word |= (uint32_t)c << b;
+        amb |= (uint32_t)(!c && !(df > thr_hi)) << b;  // ambiguous band or NaN
       }
+      const int jend = min(32, nt - w0);
+      const uint32_t vmask = jend >= 32 ? 0xFFFFFFFFu : ((1u << jend) - 1u);
+      word &= vmask;
+      amb &= vmask;
+      while (amb) {  // rare: exact fp64 evaluation
+        const int b = __ffs(amb) - 1;
+        amb &= amb - 1;
+        const int j = j0 + w0 + b;
+        const double* rj = pb.m_rxyz + (mb + j) * 3;
+        const double* tj = pb.m_xyz + (mb + j) * 3;
+        double ex = rj[0] - r1x, ey = rj[1] - r1y, ez = rj[2] - r1z;
+        const double rdd = sqrt(ex * ex + (ey * ey + ez * ez));
+        ex = tj[0] - t1x; ey = tj[1] - t1y; ez = tj[2] - t1z;
+        const double tdd = sqrt(ex * ex + (ey * ey + ez * ez));
+        if (fabs(rdd - tdd) < thr) word |= 1u << b;
+      }
+      const int self = i - (j0 + w0);
+      if (self >= 0 && self < 32) word &= ~(1u << self);
       degree += __popc(word);
       if (live) row[(j0 + w0) >> 5] = word;
     }
@@ -676,7 +686,7 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
 // grid (n_pairs), 64 threads (one wave); dynamic LDS = mcap*16 + cwords*4 + 1024.
 __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
   extern __shared__ __align__(16) uint8_t lds[];
-  const int pair = blockIdx.x, lane = threadIdx.x;
+  const int pair = blockIdx.x + pb.pair0, lane = threadIdx.x;
   if (!pb.active[pair]) return;
   uint32_t* keys = reinterpret_cast<uint32_t*>(lds);
   uint32_t* acc = keys + pb.mcap;
@@ -916,7 +926,7 @@ struct GnShared {
 // grid (n_pairs), 256 threads.
 __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParams ep) {
   __shared__ GnShared S;
-  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x;
   if (!pb.active[pair]) return;
   const int N = pb.n_matches[pair];
   const size_t mb = (size_t)pair * pb.mcap;

@@ -64,6 +64,11 @@ struct rvo_ctx {
   size_t ring_bytes = 0;
   hipEvent_t ring_ev[kRing] = {};
   int ring_pos = 0;
+  // auxiliary streams: chunks of a pair batch are pipelined against each other (fork/join around the main stream)
+  static const int kAux = 3;
+  hipStream_t aux[kAux] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[kAux] = {};
+  int pair_chunks = 2;
   // profiling
   bool prof = false;
   std::vector<std::string> prof_names;
@@ -124,21 +129,22 @@ static void prof_drain(rvo_ctx* c) {
   c->prof_recs.clear();
 }
 
-#define LAUNCH(c, NAME, KERNEL, GRID, BLOCK, SHMEM, ...)                                  \
+#define LAUNCH_ON(c, STREAM, NAME, KERNEL, GRID, BLOCK, SHMEM, ...)                       \
   do {                                                                                    \
     ProfRec pr_;                                                                          \
     if ((c)->prof) {                                                                      \
       pr_.name = prof_id((c), NAME);                                                      \
       pr_.a = get_event(c);                                                               \
       pr_.b = get_event(c);                                                               \
-      (void)hipEventRecord(pr_.a, (c)->stream);                                           \
+      (void)hipEventRecord(pr_.a, (STREAM));                                              \
     }                                                                                     \
-    hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, (c)->stream, __VA_ARGS__);             \
+    hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, (STREAM), __VA_ARGS__);                \
     if ((c)->prof) {                                                                      \
-      (void)hipEventRecord(pr_.b, (c)->stream);                                           \
+      (void)hipEventRecord(pr_.b, (STREAM));                                              \
       (c)->prof_recs.push_back(pr_);                                                      \
     }                                                                                     \
   } while (0)
+#define LAUNCH(c, NAME, KERNEL, GRID, BLOCK, SHMEM, ...) LAUNCH_ON(c, (c)->stream, NAME, KERNEL, GRID, BLOCK, SHMEM, __VA_ARGS__)
 
 // ---------------------------------------------------------------- defaults (settings.hpp:11-52)
 void rvo_default_vo_params(rvo_params* p) {
@@ -239,6 +245,12 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   for (int i = 0; i < rvo_ctx::kRing; i++) HIPCHK(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
   HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
+  for (int i = 0; i < rvo_ctx::kAux; i++) {
+    HIPCHK(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+  }
+  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  if (const char* e = getenv("RVO_PAIR_CHUNKS")) c->pair_chunks = std::max(1, std::min(rvo_ctx::kAux + 1, atoi(e)));
   FrameBufs& fb = c->fb;
   const size_t F = max_frames;
   rc |= dalloc(c, &fb.img, F * g.img_bytes);
@@ -288,6 +300,11 @@ void rvo_destroy(rvo_ctx* c) {
   if (c->d_gray_stage) (void)hipFree(c->d_gray_stage);
   if (c->d_depth_stage) (void)hipFree(c->d_depth_stage);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  for (int i = 0; i < rvo_ctx::kAux; i++) {
+    if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
+    if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   delete c;
 }
 

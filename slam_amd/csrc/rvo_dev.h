@@ -83,6 +83,7 @@ struct PairBufs {
   uint32_t* cbits;     // [pairs][mcap][cwords] consistency bit matrix
   rvo_pair_result* result;  // [pairs]
   int mcap, cwords;
+  int pair0;           // first pair work area of this launch (chunks of a batch run on different HIP streams)
 };
 
 struct CamParams {
