@@ -164,16 +164,6 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
 }
 
 // ------------------------------------------------------------------ FAST-9
-// 9 contiguous set bits in a cyclic 16-bit mask
-__device__ inline bool has9(uint32_t m) {
-  uint32_t d = m | (m << 16);
-  uint32_t r = d & (d >> 1);
-  r &= r >> 2;
-  r &= r >> 4;
-  r &= d >> 8;
-  return (r & 0xFFFFu) != 0;
-}
-
 // Segment test of fast9Detect (feature.cpp:3033-5953; equivalence with the generated tree is checked
 // exhaustively by oracle/check_fast_tree.py) and fast9CornerScore (feature.cpp:67-2995): the binary
 // search returns the largest b for which the test passes = A-1, A = max over the 16 nine-arcs of the
@@ -184,15 +174,6 @@ __device__ inline void fast9_ring_diffs(const uint8_t* t, int pitch, int* d) {
   d[4] = t[3] - p;               d[5] = t[-pitch + 3] - p;      d[6] = t[-2 * pitch + 2] - p;  d[7] = t[-3 * pitch + 1] - p;
   d[8] = t[-3 * pitch] - p;      d[9] = t[-3 * pitch - 1] - p;  d[10] = t[-2 * pitch - 2] - p; d[11] = t[-pitch - 3] - p;
   d[12] = t[-3] - p;             d[13] = t[pitch - 3] - p;      d[14] = t[2 * pitch - 2] - p;  d[15] = t[3 * pitch - 1] - p;
-}
-__device__ inline bool fast9_is_corner(const int* d, int b) {
-  uint32_t br = 0, dk = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    br |= (uint32_t)(d[i] > b) << i;
-    dk |= (uint32_t)(d[i] < -b) << i;
-  }
-  return has9(br) || has9(dk);
 }
 // A = score + 1 (only meaningful for corners: A > b)
 __device__ inline int fast9_A(const int* d) {
@@ -212,16 +193,18 @@ __device__ inline int fast9_A(const int* d) {
   return max(best_lo, -best_hi);
 }
 
-// append `val` for the lanes with pass == true to an LDS queue (order irrelevant); wave-aggregated counter bump
-__device__ inline void lds_queue_push(bool pass, uint16_t val, uint16_t* q, int* count) {
-  const unsigned long long m = __ballot(pass);
-  if (m) {
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, 0, 64);
-    if (pass) q[base + __popcll(m & ((1ull << lane) - 1ull))] = val;
-  }
+// compass test of phase A on two pixels held in the u16 halves of each operand: corner candidates need
+// min(max(n,s), max(e,w)) > p + b  or  max(min(n,s), min(e,w)) < p - b.  Non-zero half = pass.
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t compass2(uint32_t p, uint32_t n, uint32_t s, uint32_t e, uint32_t w, uint32_t b2) {
+  const us2_t P = __builtin_bit_cast(us2_t, p), N = __builtin_bit_cast(us2_t, n), S = __builtin_bit_cast(us2_t, s);
+  const us2_t E = __builtin_bit_cast(us2_t, e), W = __builtin_bit_cast(us2_t, w), B = __builtin_bit_cast(us2_t, b2);
+  const us2_t hi = P + B;
+  const us2_t lo = __builtin_elementwise_sub_sat(P, B);
+  const us2_t brv = __builtin_elementwise_min(__builtin_elementwise_max(N, S), __builtin_elementwise_max(E, W));
+  const us2_t dkv = __builtin_elementwise_max(__builtin_elementwise_min(N, S), __builtin_elementwise_min(E, W));
+  const us2_t r = __builtin_elementwise_sub_sat(brv, hi) | __builtin_elementwise_sub_sat(lo, dkv);
+  return __builtin_bit_cast(uint32_t, r);
 }
 
 struct FastLds {  // byte offsets into dynamic LDS, computed on the host (all multiples of 4)
@@ -287,39 +270,49 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   // ---- FAST, phase A: cheap necessary test on the 4 compass ring pixels for every pixel of the cell + 1 px halo.
   // A 9-arc of the 16-ring contains at least one pixel of each antipodal pair, so a corner needs
   // (p0|p8) & (p4|p12) all brighter than p+b, or all darker than p-b.  Survivors are queued in LDS as (sy<<8|sx).
-  // Thread t owns pixels t, t+256, ... (<= 64 of them): pass bits are collected in a register mask first (independent
-  // LDS reads, no per-iteration atomics), then each wave reserves queue space with ONE atomicAdd.
+  // Thread t owns four-pixel groups t, t+256, ... (<= 16 of them): pass bits are collected in a register mask first
+  // (independent LDS reads, no per-iteration atomics), then each wave reserves queue space with ONE atomicAdd.
   const int sw = cw + 2, sh = ch + 2;
-  const int npix = sw * sh;
   uint16_t* s_cand = reinterpret_cast<uint16_t*>(s_list);  // aliases the survivor list (used after later barriers)
-  uint16_t* s_corner = s_cand + (npix + 1) / 2;             // second half: queue of true corners
   int* s_ncand = s_misc + 8;
-  int* s_ncorner = s_misc + 9;
   uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_misc + 16);  // NMS survivor bitmap, one bit per cell pixel (raster)
   const int P = cw * ch;
   const int nwords = (P + 31) >> 5;
-  if (tid == 0) { *s_ncand = 0; *s_ncorner = 0; }
+  if (tid == 0) *s_ncand = 0;
   for (int w = tid; w < nwords; w += 256) s_bits[w] = 0;
+  for (int w = tid; w < (L.off_list - L.off_score) / 4; w += 256) reinterpret_cast<uint32_t*>(s_score)[w] = 0;
   __syncthreads();
   const int lane = tid & 63;
   {
-    const int q = 256 / sw, rr = 256 % sw;
-    const int sy0 = tid / sw, sx0 = tid % sw;   // score-tile coords; cell pixel = (sx-1, sy-1)
+    // 4 horizontally adjacent pixels per iteration: 5 aligned LDS dwords (centre, left, right, 3 rows up, 3 rows down)
+    // feed two packed-u16 evaluations (even / odd bytes).  Group j of score row sy covers tile x = 4j..4j+3.
+    const int ngr = (sw + 2) / 4 + 1;
+    const int q = 256 / ngr, rr = 256 % ngr;
+    const int gsy0 = tid / ngr, gj0 = tid % ngr;
+    const int txlo = max(3, 7 - cx0), txhi = min(sw + 2, G.w - cx0);  // fast9Detect loop bounds, feature.cpp:3042-3043
+    const uint32_t b2 = (uint32_t)b | ((uint32_t)b << 16);
     unsigned long long mask = 0;
-    int sy = sy0, sx = sx0;
+    int sy = gsy0, j = gj0;
     for (int k = 0; sy < sh; k++) {
-      const int gx = cx0 + sx - 1, gy = cy0 + sy - 1;
-      s_score[sy * SP + sx] = 0;
-      if (gx >= 3 && gx <= G.w - 4 && gy >= 3 && gy <= G.h - 4) {  // fast9Detect loop bounds, feature.cpp:3042-3043
-        const uint8_t* t = s_tile + (sy + 3) * TP + (sx + 3);
-        const int p = t[0];
-        const int d0 = t[3 * TP] - p, d4 = t[3] - p, d8 = t[-3 * TP] - p, d12 = t[-3] - p;
-        const bool br = ((d0 > b) | (d8 > b)) & ((d4 > b) | (d12 > b));
-        const bool dk = ((d0 < -b) | (d8 < -b)) & ((d4 < -b) | (d12 < -b));
-        mask |= (unsigned long long)(br | dk) << k;
+      const int gy = cy0 + sy - 1;
+      if (gy >= 3 && gy <= G.h - 4) {
+        const uint8_t* row = s_tile + (sy + 3) * TP + 4 * j;
+        const uint32_t C = *reinterpret_cast<const uint32_t*>(row);
+        const uint32_t Lw = *reinterpret_cast<const uint32_t*>(row - 4);
+        const uint32_t R = *reinterpret_cast<const uint32_t*>(row + 4);
+        const uint32_t U = *reinterpret_cast<const uint32_t*>(row - 3 * TP);
+        const uint32_t D = *reinterpret_cast<const uint32_t*>(row + 3 * TP);
+        const uint32_t W = __builtin_amdgcn_alignbyte(C, Lw, 1);  // tile x-3 of the four pixels
+        const uint32_t E = __builtin_amdgcn_alignbyte(R, C, 3);   // tile x+3
+        const uint32_t M = 0x00FF00FFu;
+        const uint32_t re = compass2(C & M, D & M, U & M, E & M, W & M, b2);
+        const uint32_t ro = compass2((C >> 8) & M, (D >> 8) & M, (U >> 8) & M, (E >> 8) & M, (W >> 8) & M, b2);
+        const uint32_t bits = ((re & 0xFFFFu) ? 1u : 0u) | ((ro & 0xFFFFu) ? 2u : 0u) | ((re >> 16) ? 4u : 0u) | ((ro >> 16) ? 8u : 0u);
+        const uint32_t vm = (0xFu << min(max(txlo - 4 * j, 0), 4)) & (0xFu >> min(max(4 * j + 3 - txhi, 0), 4));
+        mask |= (unsigned long long)(bits & vm & 0xFu) << (4 * k);
       }
-      sx += rr; sy += q;
-      if (sx >= sw) { sx -= sw; sy++; }
+      j += rr; sy += q;
+      if (j >= ngr) { j -= ngr; sy++; }
     }
     // wave-level reservation
     const int mine = __popcll(mask);
@@ -330,46 +323,33 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     int base = 0;
     if (lane == 0 && wtot) base = atomicAdd(s_ncand, wtot);
     base = __shfl(base, 0, 64) + inc - mine;
-    sy = sy0; sx = sx0;
-    for (int k = 0; mask >> k; k++) {
-      if ((mask >> k) & 1ull) s_cand[base++] = (uint16_t)((sy << 8) | sx);
-      sx += rr; sy += q;
-      if (sx >= sw) { sx -= sw; sy++; }
+    sy = gsy0; j = gj0;
+    for (int k = 0; k < 16 && (mask >> (4 * k)); k++) {
+      uint32_t bits = (uint32_t)(mask >> (4 * k)) & 0xFu;
+      while (bits) {
+        const int i = __ffs(bits) - 1;
+        bits &= bits - 1;
+        s_cand[base++] = (uint16_t)((sy << 8) | (4 * j + i - 3));
+      }
+      j += rr; sy += q;
+      if (j >= ngr) { j -= ngr; sy++; }
     }
   }
   __syncthreads();
-  // ---- phase B: full segment test on the queued pixels; phase C: score for the true corners.  Both run with
-  // all lanes busy.  If more than half of the pixels were queued (dense noise) the two queues do not fit and
-  // the score is computed directly in phase B.
+  // ---- phase B: score A = fast9CornerScore + 1 for every queued pixel; it is a corner iff A > b (the segment
+  // test passes at threshold b iff b < A).  All lanes busy; measured faster than a separate detect pass.
   const int ncand = *s_ncand;
-  const bool two_queues = ncand <= npix / 2;
-  for (int c0 = 0; c0 < ncand; c0 += 256) {
-    const int c = c0 + tid;
-    bool corner = false;
-    uint16_t v = 0;
-    if (c < ncand) {
-      v = s_cand[c];
-      const int sy = v >> 8, sx = v & 255;
-      int d[16];
-      fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3), TP, d);
-      corner = fast9_is_corner(d, b);
-      if (corner && !two_queues) s_score[sy * SP + sx] = (uint8_t)fast9_A(d);
-    }
-    if (two_queues) lds_queue_push(corner, v, s_corner, s_ncorner);
+  for (int c = tid; c < ncand; c += 256) {
+    const uint16_t v = s_cand[c];
+    const int sy = v >> 8, sx = v & 255;
+    int d[16];
+    fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3), TP, d);
+    const int A = fast9_A(d);
+    if (A > b) s_score[sy * SP + sx] = (uint8_t)A;
   }
   __syncthreads();
-  const int nlist = two_queues ? *s_ncorner : ncand;
-  const uint16_t* s_qlist = two_queues ? s_corner : s_cand;
-  if (two_queues) {
-    for (int c = tid; c < nlist; c += 256) {
-      const uint16_t v = s_qlist[c];
-      const int sy = v >> 8, sx = v & 255;
-      int d[16];
-      fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3), TP, d);
-      s_score[sy * SP + sx] = (uint8_t)fast9_A(d);
-    }
-    __syncthreads();
-  }
+  const int nlist = ncand;
+  const uint16_t* s_qlist = s_cand;
 
   // ---- NMS (feature.cpp:5960-6056: a corner survives iff no 8-neighbour corner has score >= its own) on the
   // queued pixels only; survivors set one bit of a raster-ordered bitmap of the cell.
@@ -425,7 +405,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   }
 }
 
-// ------------------------------------------------------------------ keypoint records + descriptors + XYZ
+// ------------------------------------------------------------------ keypoint records + XYZ
 // grid (levels, n_frames), 256 threads.
 __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots) {
   __shared__ int s_wave[4];
@@ -501,32 +481,59 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
     base += total;
   }
   if (tid == 0) fb.kp_cnt[slot * RVO_MAX_LEVELS + lvl] = base;
-  __syncthreads();  // kp_uvs written by this block are re-read below (same workgroup: L1-coherent after barrier)
-  __threadfence_block();
+}
 
-  // descriptors: one wave per keypoint; ExtractAlignedDescriptor + Normalized twice (feature.cpp:6140-6156, 6193-6207)
-  for (int kp = wid; kp < base; kp += 4) {
-    const uint32_t k = fb.kp_uvs[kbase + kp];
-    const int x = kp_x(k), y = kp_y(k);
-    int v0 = img[(size_t)(y + lane / 9 - 4) * G.stride + (x + lane % 9 - 4)];
-    int v1 = 0;
-    const int t1 = lane + 64;
-    if (lane < RVO_DESC_LEN - 64) v1 = img[(size_t)(y + t1 / 9 - 4) * G.stride + (x + t1 % 9 - 4)];
+// Descriptors (ExtractAlignedDescriptor + Normalized twice, feature.cpp:6140-6156, 6193-6207).
+// grid (ceil(kp_total/DESC_PER_BLOCK), n_frames), 256 threads = 16 groups of 16 lanes; a group extracts one
+// keypoint per round.  Lane l owns descriptor dword l (taps 4l..4l+3); lanes 0-3 also own dwords 16-19, so every
+// store is one aligned dword.  Runs after k_build_keypoints (reads kp_uvs / kp_cnt).
+#define DESC_PER_BLOCK 32
+__device__ inline int sum16(int v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+  return v;
+}
+__global__ __launch_bounds__(256) void k_descriptors(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots) {
+  const int slot = slots[blockIdx.y];
+  if (slot < 0) return;
+  const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+  // tap offsets of this lane (row-major over the 9x9 window, last pixel dropped)
+  int oy[8], ox[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    const int t = (m < 4 ? 4 * sub : 64 + 4 * sub) + (m & 3);
+    oy[m] = t / 9 - 4; ox[m] = t % 9 - 4;
+  }
+  const bool two = sub < (RVO_DESC_LEN - 64) / 4;
+#pragma unroll
+  for (int r = 0; r < DESC_PER_BLOCK / 16; r++) {
+    const int idx = blockIdx.x * DESC_PER_BLOCK + r * 16 + grp;  // keypoint slot within the frame
+    if (idx >= g.kp_total) continue;
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < RVO_MAX_LEVELS; l++)
+      if (l < g.levels && idx >= g.lv[l].kp_off) lvl = l;
+    const LevelGeom& G = g.lv[lvl];
+    if (idx - G.kp_off >= fb.kp_cnt[slot * RVO_MAX_LEVELS + lvl]) continue;  // uniform within the 16-lane group
+    const uint8_t* __restrict__ img = fb.img + (size_t)slot * g.img_bytes + G.img_off;
+    const size_t kidx = (size_t)slot * g.kp_total + idx;
+    const uint32_t k = fb.kp_uvs[kidx];
+    const uint8_t* c = img + (size_t)kp_y(k) * G.stride + kp_x(k);
+    int v[8];
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = c[oy[m] * G.stride + ox[m]];
+#pragma unroll
+    for (int m = 4; m < 8; m++) v[m] = two ? (int)c[oy[m] * G.stride + ox[m]] : 0;
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-      const int mean = wave_sum(v0 + v1) / RVO_DESC_LEN;
-      if (mean < 128) {
-        const int o = 128 - mean;
-        v0 = min(255, v0 + o);
-        if (lane < RVO_DESC_LEN - 64) v1 = min(255, v1 + o);
-      } else if (mean > 128) {
-        const int o = mean - 128;
-        v0 = max(0, v0 - o);
-        if (lane < RVO_DESC_LEN - 64) v1 = max(0, v1 - o);
-      }
+      const int mean = sum16(v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]) / RVO_DESC_LEN;
+      const int o = 128 - mean;  // mean < 128: add and clamp at 255; mean > 128: subtract and clamp at 0
+#pragma unroll
+      for (int m = 0; m < 8; m++) v[m] = min(255, max(0, v[m] + o));
+      if (!two) { v[4] = v[5] = v[6] = v[7] = 0; }
     }
-    uint8_t* dsc = fb.kp_desc + (kbase + kp) * RVO_DESC_LEN;
-    dsc[lane] = (uint8_t)v0;
-    if (lane < RVO_DESC_LEN - 64) dsc[t1] = (uint8_t)v1;
+    uint32_t* dsc = reinterpret_cast<uint32_t*>(fb.kp_desc + kidx * RVO_DESC_LEN);
+    dsc[sub] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+    if (two) dsc[16 + sub] = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
   }
 }

@@ -237,7 +237,9 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   // the same region first holds the phase-A candidate queue: u16 per pixel of the (gw+2)x(gh+2) score region
   fl.off_misc = fl.off_list + round_up(std::max(fl.list_cap * 4, (g.gw + 2) * (g.gh + 2) * 2 + 4), 16);
   fl.total = fl.off_misc + 64 + round_up((g.gw * g.gh + 31) / 32 * 4, 16);
-  if (fl.total > 150 * 1024 || g.gw + 2 > 255 || g.gh + 2 > 255 || (g.gw + 2) * (g.gh + 2) > 64 * 256) { g_err = "grid cell too large for LDS"; delete c; return RVO_E_UNSUPPORTED; }
+  if (fl.total > 150 * 1024 || g.gw + 2 > 255 || g.gh + 2 > 255 || (g.gw + 2) * (g.gh + 2) > 64 * 256 ||
+      ((g.gw + 4) / 4 + 1) * (g.gh + 2) > 16 * 256) {  // phase A of k_fast_grid: <= 16 four-pixel groups per thread
+    g_err = "grid cell too large for LDS"; delete c; return RVO_E_UNSUPPORTED; }
 
   int rc = 0;
   c->ring_bytes = std::max<size_t>(4096, (size_t)std::max(max_frames, max_pairs) * 12 * 8);
@@ -352,6 +354,7 @@ static int enqueue_prepare(rvo_ctx* c, int n, const int32_t* d_slots, const int3
   }
   LAUNCH(c, "fast_grid", k_fast_grid, dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
   LAUNCH(c, "build_keypoints", k_build_keypoints, dim3(g.levels, n), dim3(256), 0, c->fb, g, d_slots);
+  LAUNCH(c, "descriptors", k_descriptors, dim3((g.kp_total + DESC_PER_BLOCK - 1) / DESC_PER_BLOCK, n), dim3(256), 0, c->fb, g, d_slots);
   HIPCHK(hipGetLastError());
   return RVO_OK;
 }
