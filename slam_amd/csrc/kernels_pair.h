@@ -708,9 +708,7 @@ __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
   for (int w = lane; w < nw; w += 64) acc[w] = 0;
   __syncthreads();
   // std::sort(_matches, _matches+N, consistencyCompare): unstable, replayed exactly
-#ifndef ABL_NOSORT
   wavealgo::wave_sort<16>(keys, N, li, ri, ls, le, tmp, stack);
-#endif
   __syncthreads();
   for (int i = lane; i < N; i += 64) pb.order[mb + i] = keys[i];
 
@@ -722,20 +720,19 @@ __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
   const int pitch = nw | 1;             // odd pitch: lane-strided reads are conflict-free
   int num_inl = 0;
   bool stop = false;
-#ifdef ABL_NOGREEDY
-  stop = true;
-#endif
   // When a row fits one word per lane (N <= 2048) the next round's 64 rows are fetched into registers while the
   // current round is resolved (the candidate order is already fixed by the sort), hiding the HBM/L2 round trip.
   const bool pipelined = nw <= 64;
   uint32_t pre[64];
+  const uint32_t* __restrict__ cb = pb.cbits + mb * pb.cwords;  // wave-uniform base: rows are addressed with 32-bit offsets
+  const uint32_t cw = (uint32_t)pb.cwords;
   auto fetch = [&](int c0) {
     const int mm = c0 + lane;
     const int idl = (mm < N) ? (int)(keys[mm] & 0xFFFF) : 0;
 #pragma unroll
     for (int u = 0; u < 64; u++) {
-      const int idk = __shfl(idl, u, 64);
-      pre[u] = (lane < nw) ? pb.cbits[(mb + idk) * pb.cwords + lane] : 0u;
+      const uint32_t idk = (uint32_t)__builtin_amdgcn_readlane(idl, u);
+      pre[u] = (lane < nw) ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(cb) + (idk * cw + (uint32_t)lane) * 4u) : 0u;
     }
   };
   if (pipelined && !stop) fetch(0);
@@ -776,26 +773,48 @@ __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
       for (int w = 0; w < nw; w++) bad |= acc[w] & ~row[w];
       ok = valid && bad == 0;
     }
-    // wave-uniform lane indices: v_readlane (a few cycles), not the LDS-crossbar shuffle
-#pragma unroll 8
-    for (int k = 0; k < kmax; k++) {
-      const int idk = __builtin_amdgcn_readlane(id, k);
-      cm |= (unsigned long long)((row[idk >> 5] >> (idk & 31)) & 1u) << k;
-    }
-    const unsigned long long okm0 = __ballot(ok);  // lanes that are consistent with all earlier rounds
-    unsigned long long alive = okm0;                // updated as candidates of this round are accepted
-    for (int k = 0; k < kmax; k++) {
-      const int degk = __builtin_amdgcn_readlane(deg, k);
-      if (degk < num_inl) { stop = true; break; }
-      if ((alive >> k) & 1ull) {
-        num_inl++;
-        // everyone inconsistent with candidate k drops out: bit k of lane j's cm == consistent(j, k)
-        alive &= __ballot((cm >> k) & 1ull) | (1ull << k);
-        if (lane == k) {
-          acc[id >> 5] |= 1u << (id & 31);
-          pb.m_inlier[mb + id] = 1;
+    // cm bit k of lane j = consistent(candidate j, candidate k).  Wave-uniform lane indices come from v_readlane;
+    // the 64 LDS reads are issued in independent batches of 16 (lanes k >= kmax carry id 0: harmless, never alive).
+    {
+      uint32_t half[2] = {0u, 0u};
+#pragma unroll
+      for (int k0 = 0; k0 < 64; k0 += 16) {
+        uint32_t wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) wv[u] = row[(uint32_t)__builtin_amdgcn_readlane(id, k0 + u) >> 5];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const uint32_t sh = (uint32_t)__builtin_amdgcn_readlane(id, k0 + u) & 31u;
+          half[k0 >> 5] |= ((wv[u] >> sh) & 1u) << ((k0 + u) & 31);
         }
       }
+      cm = (unsigned long long)half[0] | ((unsigned long long)half[1] << 32);
+    }
+    // In-round order dependence without a serial walk over the 64 candidates: the lowest alive lane that is
+    // inconsistent with an earlier alive lane is rejected (every alive lane before it is accepted); repeat until no
+    // conflict is left.  Iterations = candidates rejected inside the round, typically a handful.
+    unsigned long long alive = __ballot(ok);  // consistent with every inlier of the earlier rounds
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (;;) {
+      const bool conf = ((alive >> lane) & 1ull) && ((~cm & alive & lt) != 0ull);
+      const unsigned long long cmask = __ballot(conf);
+      if (!cmask) break;
+      alive &= ~(1ull << (__ffsll((long long)cmask) - 1));
+    }
+    // the walk stops at the first candidate (accepted or not) whose degree is below the clique size reached before it
+    unsigned long long accepted = alive;
+    {
+      const int before = num_inl + __popcll(alive & lt);
+      const unsigned long long sm = __ballot(lane < kmax && deg < before);
+      if (sm) {
+        accepted &= (1ull << (__ffsll((long long)sm) - 1)) - 1ull;
+        stop = true;
+      }
+    }
+    num_inl += __popcll(accepted);
+    if ((accepted >> lane) & 1ull) {
+      atomicOr(&acc[id >> 5], 1u << (id & 31));
+      pb.m_inlier[mb + id] = 1;
     }
     __syncthreads();
   }
