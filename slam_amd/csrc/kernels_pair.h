@@ -683,15 +683,19 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
 }
 
 // ------------------------------------------------------------------ sort + greedy clique
-// grid (n_pairs), 64 threads (one wave); dynamic LDS = mcap*16 + cwords*4 + 1024.
-__global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
+// grid (n_pairs), CLIQUE_WAVES*64 threads; dynamic LDS = clique_lds_bytes(mcap, cwords).  All waves sort; wave 0
+// then walks the sorted candidates.
+#define CLIQUE_WAVES 4
+__host__ __device__ inline int clique_ctl_ints() { return 4 + SORT_QCAP * 2 + CLIQUE_WAVES * SORT_STACK * 2; }
+__host__ __device__ inline int clique_lds_bytes(int mcap, int cwords) { return mcap * 16 + cwords * 4 + clique_ctl_ints() * 4 + 64; }
+__global__ __launch_bounds__(CLIQUE_WAVES * 64) void k_clique(PairBufs pb) {
   extern __shared__ __align__(16) uint8_t lds[];
-  const int pair = blockIdx.x + pb.pair0, lane = threadIdx.x;
+  const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x, lane = tid & 63;
   if (!pb.active[pair]) return;
   uint32_t* keys = reinterpret_cast<uint32_t*>(lds);
   uint32_t* acc = keys + pb.mcap;
-  int* stack = reinterpret_cast<int*>(acc + pb.cwords);
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(stack + 128);
+  int* ctl = reinterpret_cast<int*>(acc + pb.cwords);
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(ctl + clique_ctl_ints());
   uint16_t* li = reinterpret_cast<uint16_t*>(tmp + pb.mcap);
   uint16_t* ri = li + pb.mcap;
   uint16_t* ls = ri + pb.mcap;
@@ -700,17 +704,17 @@ __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
   const size_t mb = (size_t)pair * pb.mcap;
   rvo_pair_result* res = pb.result + pair;
   if (N == 0) {  // computeMaximallyConsistentClique returns early (motion_estimate.cpp:444-445); 0 inliers
-    if (lane == 0) res->num_inliers = 0;
+    if (tid == 0) res->num_inliers = 0;
     return;
   }
-  for (int i = lane; i < N; i += 64) keys[i] = ((uint32_t)pb.m_degree[mb + i] << 16) | (uint32_t)i;
+  for (int i = tid; i < N; i += CLIQUE_WAVES * 64) keys[i] = ((uint32_t)pb.m_degree[mb + i] << 16) | (uint32_t)i;
   const int nw = (N + 31) >> 5;
-  for (int w = lane; w < nw; w += 64) acc[w] = 0;
+  for (int w = tid; w < nw; w += CLIQUE_WAVES * 64) acc[w] = 0;
   __syncthreads();
   // std::sort(_matches, _matches+N, consistencyCompare): unstable, replayed exactly
-  wavealgo::wave_sort<16>(keys, N, li, ri, ls, le, tmp, stack);
-  __syncthreads();
-  for (int i = lane; i < N; i += 64) pb.order[mb + i] = keys[i];
+  wavealgo::block_sort<16>(keys, N, li, ri, ls, le, tmp, ctl);
+  for (int i = tid; i < N; i += CLIQUE_WAVES * 64) pb.order[mb + i] = keys[i];
+  if (tid >= 64) return;  // the walk below is one wave; LDS accesses of one wave are ordered, so it needs no barrier
 
   // greedy clique, motion_estimate.cpp:529-569, 64 candidates per round.  The 64 candidates' rows of the bit
   // matrix are first copied into LDS with coalesced loads (the sort scratch is dead by now and is reused); lane k
@@ -746,7 +750,7 @@ __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
 #pragma unroll
       for (int u = 0; u < 64; u++)
         if (lane < nw) srow[u * pitch + lane] = pre[u];
-      __syncthreads();
+      wavealgo::wave_lds_sync();
       if (c0 + 64 < N) fetch(c0 + 64);
     } else {
       for (int w = lane; w < nw + ((-nw) & 63); w += 64) {  // wave-uniform trip count
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
             if (w < nw) srow[(k0 + u) * pitch + w] = v[u];
         }
       }
-      __syncthreads();
+      wavealgo::wave_lds_sync();
     }
     const uint32_t* row = srow + lane * pitch;
     bool ok = valid;
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(64) void k_clique(PairBufs pb) {
       atomicOr(&acc[id >> 5], 1u << (id & 31));
       pb.m_inlier[mb + id] = 1;
     }
-    __syncthreads();
+    wavealgo::wave_lds_sync();
   }
   if (lane == 0) res->num_inliers = num_inl;
 }
@@ -1331,7 +1335,7 @@ __global__ void k_stream_post2(StreamState* st, int n, StreamParams sp, PairBufs
 }
 
 // ------------------------------------------------------------------ self-test of wave_stdalgo.h (one wave)
-__global__ __launch_bounds__(64) void k_selftest_stdalgo(uint32_t* keys, int n, int shift, int nth) {
+__global__ __launch_bounds__(CLIQUE_WAVES * 64) void k_selftest_stdalgo(uint32_t* keys, int n, int shift, int nth) {
   extern __shared__ __align__(16) uint8_t lds[];
   uint32_t* a = reinterpret_cast<uint32_t*>(lds);
   uint32_t* tmp = a + n;
@@ -1339,16 +1343,16 @@ __global__ __launch_bounds__(64) void k_selftest_stdalgo(uint32_t* keys, int n, 
   uint16_t* ri = li + n;
   uint16_t* ls = ri + n;
   uint16_t* le = ls + n;
-  int* stack = reinterpret_cast<int*>(le + n + (n & 1));
-  for (int i = threadIdx.x; i < n; i += 64) a[i] = keys[i];
+  int* ctl = reinterpret_cast<int*>(le + n);  // 16*n bytes in: 4-byte aligned
+  for (int i = threadIdx.x; i < n; i += blockDim.x) a[i] = keys[i];
   __syncthreads();
   if (nth < 0) {
-    if (shift == 16) wavealgo::wave_sort<16>(a, n, li, ri, ls, le, tmp, stack);
-    else wavealgo::wave_sort<22>(a, n, li, ri, ls, le, tmp, stack);
-  } else {
+    if (shift == 16) wavealgo::block_sort<16>(a, n, li, ri, ls, le, tmp, ctl);
+    else wavealgo::block_sort<22>(a, n, li, ri, ls, le, tmp, ctl);
+  } else if (threadIdx.x < 64) {
     if (shift == 16) wavealgo::wave_nth_element<16>(a, nth, n, li, ri);
     else wavealgo::wave_nth_element<22>(a, nth, n, li, ri);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 64) keys[i] = a[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) keys[i] = a[i];
 }

@@ -114,25 +114,70 @@ __device__ inline void wave_nth_element(uint32_t* a, int nth, int n, uint16_t* l
   wave_lds_sync();
 }
 
-// std::sort(a, a+n, comp).  Scratch: li, ri (u16[n]); leaf_s, leaf_e (u16[n]); tmp (u32[n]); stack (int[128]).
+// std::sort(a, a+n, comp) by all waves of the workgroup (blockDim.x = 64 * NW, every thread calls).
+// __introsort_loop (stl_algo.h:1940-1958) recurses on [cut, last) and loops on [first, cut): the two ranges are
+// independent, so the recursion becomes a work queue: a wave partitions its range, publishes the right part in a
+// shared LDS queue (or, when the queue is full, on its own small stack, whose depth is bounded by the depth limit
+// 2*lg(n)) and continues with the left part.  The order in which ranges are processed does not change the result.
+// Scratch: li, ri, leaf_s, leaf_e (u16[n] each; the partition of [first,last) only uses li/ri[first..last)), tmp
+// (u32[n]), ctl (int[4 + SORT_QCAP*2 + NW*SORT_STACK*2]).
+#define SORT_QCAP 1024
+#define SORT_STACK 32
+__device__ inline int sort_ctl_ints(int nwaves) { return 4 + SORT_QCAP * 2 + nwaves * SORT_STACK * 2; }
+
 template <int SHIFT>
-__device__ inline void wave_sort(uint32_t* a, int n, uint16_t* li, uint16_t* ri, uint16_t* leaf_s, uint16_t* leaf_e,
-                                 uint32_t* tmp, int* stack) {
-  const int lane = threadIdx.x & 63;
+__device__ inline void block_sort(uint32_t* a, int n, uint16_t* li, uint16_t* ri, uint16_t* leaf_s, uint16_t* leaf_e,
+                                  uint32_t* tmp, int* ctl) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthreads = blockDim.x;
   KeyGreater<SHIFT> comp;
   if (n == 0) return;
+  int* head = ctl;          // next queue entry to claim
+  int* tail = ctl + 1;      // reserved queue entries
+  int* pending = ctl + 2;   // ranges published or being processed
+  uint32_t* q_seg = reinterpret_cast<uint32_t*>(ctl + 4);  // first | last << 16; 0 = not yet written
+  int* q_depth = ctl + 4 + SORT_QCAP;
+  int* stk = ctl + 4 + SORT_QCAP * 2 + wid * SORT_STACK * 2;
+  for (int i = tid; i < SORT_QCAP; i += nthreads) q_seg[i] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    *head = 0; *tail = 1; *pending = 1;
+    q_depth[0] = stdalgo::lg_(n) * 2;
+    q_seg[0] = (uint32_t)n << 16;
+  }
+  __syncthreads();
   auto mark_leaf = [&](int s, int e) {
     for (int i = s + lane; i < e; i += 64) { leaf_s[i] = (uint16_t)s; leaf_e[i] = (uint16_t)e; }
   };
-  // __introsort_loop with an explicit stack (stack accesses are wave-uniform; lane 0 writes, all lanes read)
-  int sp = 0;
-  if (lane == 0) { stack[0] = 0; stack[1] = n; stack[2] = stdalgo::lg_(n) * 2; }
-  sp = 3;
-  wave_lds_sync();
-  while (sp > 0) {
-    int depth_limit = stack[sp - 1], last = stack[sp - 2], first = stack[sp - 3];
-    sp -= 3;
-    bool heap_done = false;
+  int sp = 0;  // entries on this wave's private stack (wave-uniform)
+  for (;;) {
+    int first, last, depth_limit;
+    if (sp > 0) {
+      sp--;
+      const uint32_t seg = (uint32_t)stk[2 * sp];
+      first = seg & 0xFFFF; last = seg >> 16; depth_limit = stk[2 * sp + 1];
+    } else {
+      int h = -1;
+      uint32_t seg = 0;
+      if (lane == 0) {
+        for (;;) {
+          const int hd = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int tl = min(__hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), SORT_QCAP);
+          if (hd < tl) {
+            if (atomicCAS(head, hd, hd + 1) == hd) { h = hd; break; }
+          } else if (__hip_atomic_load(pending, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+            break;
+          } else {
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        if (h >= 0)
+          while ((seg = __hip_atomic_load(&q_seg[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __builtin_amdgcn_s_sleep(1);
+      }
+      h = __builtin_amdgcn_readfirstlane(h);
+      if (h < 0) break;
+      seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg);
+      first = seg & 0xFFFF; last = seg >> 16; depth_limit = q_depth[h];
+    }
     while (last - first > 16) {
       if (depth_limit == 0) {
         if (lane == 0) {
@@ -140,38 +185,51 @@ __device__ inline void wave_sort(uint32_t* a, int n, uint16_t* li, uint16_t* ri,
           stdalgo::sort_heap_(a, first, last, comp);
         }
         wave_lds_sync();
-        heap_done = true;
         break;
       }
       --depth_limit;
-      const int cut = wave_partition_pivot<SHIFT>(a, first, last, li, ri);
-      if (lane == 0) { stack[sp] = cut; stack[sp + 1] = last; stack[sp + 2] = depth_limit; }
-      sp += 3;
-      wave_lds_sync();
+      const int cut = wave_partition_pivot<SHIFT>(a, first, last, li + first, ri + first);
+      if (last - cut > 16) {
+        int local = 0;
+        if (lane == 0) {
+          const uint32_t seg = (uint32_t)cut | ((uint32_t)last << 16);
+          __hip_atomic_fetch_add(pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int idx = __hip_atomic_fetch_add(tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (idx < SORT_QCAP) {
+            q_depth[idx] = depth_limit;
+            __hip_atomic_store(&q_seg[idx], seg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // publishes a[] too
+          } else {
+            stk[2 * sp] = (int)seg; stk[2 * sp + 1] = depth_limit;
+            local = 1;
+          }
+        }
+        sp += __builtin_amdgcn_readfirstlane(local);
+        wave_lds_sync();
+      } else {
+        mark_leaf(cut, last);  // std recurses into it and returns at once
+      }
       last = cut;
     }
-    (void)heap_done;
     mark_leaf(first, last);  // a <=16 leaf, or a heap-sorted range (already sorted: the stable sort is the identity)
+    wave_lds_sync();
+    if (lane == 0) __hip_atomic_fetch_sub(pending, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  wave_lds_sync();
+  __syncthreads();
   // __final_insertion_sort == stable sort of every leaf
-  for (int i0 = 0; i0 < n; i0 += 64) {
-    const int i = i0 + lane;
-    if (i < n) {
-      const int s = leaf_s[i], e = leaf_e[i];
-      const uint32_t me = a[i];
-      const uint32_t mk = me >> SHIFT;
-      int rank = s;
-      for (int j = s; j < e; j++) {
-        const uint32_t k = a[j] >> SHIFT;
-        rank += (k > mk) || (k == mk && j < i);
-      }
-      tmp[rank] = me;
+  for (int i = tid; i < n; i += nthreads) {
+    const int s = leaf_s[i], e = leaf_e[i];
+    const uint32_t me = a[i];
+    const uint32_t mk = me >> SHIFT;
+    int rank = s;
+    for (int j = s; j < e; j++) {
+      const uint32_t k = a[j] >> SHIFT;
+      rank += (k > mk) || (k == mk && j < i);
     }
+    tmp[rank] = me;
   }
-  wave_lds_sync();
-  for (int i = lane; i < n; i += 64) a[i] = tmp[i];
-  wave_lds_sync();
+  __syncthreads();
+  for (int i = tid; i < n; i += nthreads) a[i] = tmp[i];
+  __syncthreads();
 }
 
 }  // namespace wavealgo
