@@ -684,8 +684,8 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
 
 // ------------------------------------------------------------------ sort + greedy clique
 // grid (n_pairs), CLIQUE_WAVES*64 threads; dynamic LDS = clique_lds_bytes(mcap, cwords).  All waves sort; wave 0
-// then walks the sorted candidates.
-#define CLIQUE_WAVES 4
+// then walks the sorted candidates (8 waves measured best).
+#define CLIQUE_WAVES 8
 __host__ __device__ inline int clique_ctl_ints() { return 4 + SORT_QCAP * 2 + CLIQUE_WAVES * SORT_STACK * 2; }
 __host__ __device__ inline int clique_lds_bytes(int mcap, int cwords) { return mcap * 16 + cwords * 4 + clique_ctl_ints() * 4 + 64; }
 __global__ __launch_bounds__(CLIQUE_WAVES * 64) void k_clique(PairBufs pb) {
