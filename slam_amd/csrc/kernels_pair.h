@@ -309,12 +309,18 @@ __device__ inline uint32_t sad80(const uint8_t* a, const uint8_t* b) {
   return s;
 }
 
-// grid (levels, n_pairs), 1024 threads; dynamic LDS = kp_cap(level 0) * 16 + MATCH_WAVES * MATCH_QCAP * 4 + 128.
-// Phase 1 (dense, fp64): every wave walks its reference keypoints against all target keypoints 64 at a time and
-// queues the (ref,target) pairs inside the search window.  Phase 2 (whenever the wave's queue fills): one lane
-// per queued pair computes the SAD and folds it into the per-ref and per-target bests with LDS atomicMin on
-// (score<<16 | index) keys -- the lexicographic minimum is exactly the reference's "strictly smaller score wins,
-// first in iteration order on ties" (feature.cpp:6301-6308).
+// grid (levels, n_pairs), 1024 threads; dynamic LDS = match_lds_bytes(kp_cap(level 0)).
+// Setup: every reference keypoint is projected once (fp64, motion_estimate.cpp:321-327) into LDS, and every run of
+// 64 target keypoints (targets are stored bucket by bucket, so a run is spatially compact) gets a bounding box.
+// Phase 1: a wave walks its reference keypoints; lanes test the run boxes against the search window, and only the
+// runs that can hold a candidate are visited, 64 targets at a time: fp32 distance first, the reference's fp64
+// err.norm() < window (motion_estimate.cpp:335) only inside the rounding band around the threshold.  In-window
+// (ref,target) pairs are queued.  Phase 2 (whenever the wave's queue fills): one lane per queued pair computes the
+// SAD and folds it into the per-ref and per-target bests with LDS atomicMin on (score<<16 | index) keys -- the
+// lexicographic minimum is exactly the reference's "strictly smaller score wins, first in iteration order on ties"
+// (feature.cpp:6301-6308).
+#define MATCH_MAX_RUNS 64
+__host__ __device__ inline int match_lds_bytes(int cap) { return cap * 16 + MATCH_MAX_RUNS * 16 + MATCH_WAVES * MATCH_QCAP * 4 + 128; }
 __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, EstParams ep) {
   extern __shared__ __align__(16) uint8_t lds[];
   const int lvl = blockIdx.x, pair = blockIdx.y + pb.pair0, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -324,8 +330,9 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom
   float2* s_tuv = reinterpret_cast<float2*>(lds);
   uint32_t* s_bt = reinterpret_cast<uint32_t*>(lds + (size_t)cap * 8);
   uint32_t* s_br = s_bt + cap;
-  uint32_t* s_q = s_br + cap + (size_t)wid * MATCH_QCAP;
-  int* s_wave = reinterpret_cast<int*>(s_br + cap + (size_t)MATCH_WAVES * MATCH_QCAP);
+  float4* s_box = reinterpret_cast<float4*>(s_br + cap);                  // per run: min u, min v, max u, max v
+  uint32_t* s_q = reinterpret_cast<uint32_t*>(s_box + MATCH_MAX_RUNS) + (size_t)wid * MATCH_QCAP;
+  int* s_wave = reinterpret_cast<int*>(reinterpret_cast<uint32_t*>(s_box + MATCH_MAX_RUNS) + (size_t)MATCH_WAVES * MATCH_QCAP);
   const int rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
   const int nr = fb.kp_cnt[rs * RVO_MAX_LEVELS + lvl], nt = fb.kp_cnt[ts * RVO_MAX_LEVELS + lvl];
   const size_t rbase = (size_t)rs * g.kp_total + G.kp_off, tbase = (size_t)ts * g.kp_total + G.kp_off;
@@ -337,12 +344,32 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom
   double RP[12];
   proj_matrix(cam.fx, cam.fy, cam.cx, cam.cy, r2t, RP);
 
-  for (int i = tid; i < nt; i += MATCH_THREADS) { s_tuv[i] = fb.kp_rect[tbase + i]; s_bt[i] = NONE_KEY; }
+  const int nruns = (nt + 63) >> 6;
+  const bool boxed = nruns <= MATCH_MAX_RUNS;
+  for (int i0 = wid * 64; i0 < nt; i0 += MATCH_THREADS) {  // whole runs per wave
+    const int i = i0 + lane;
+    float2 uv = make_float2(0.f, 0.f);
+    if (i < nt) { uv = fb.kp_rect[tbase + i]; s_tuv[i] = uv; s_bt[i] = NONE_KEY; }
+    if (boxed) {
+      float mnx = i < nt ? uv.x : INFINITY, mny = i < nt ? uv.y : INFINITY;
+      float mxx = i < nt ? uv.x : -INFINITY, mxy = i < nt ? uv.y : -INFINITY;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
+        mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+      }
+      if (lane == 0) s_box[i0 >> 6] = make_float4(mnx, mny, mxx, mxy);
+    }
+  }
   for (int i = tid; i < nr; i += MATCH_THREADS) s_br[i] = NONE_KEY;
   __syncthreads();
 
   const double win = ep.feature_search_window;
   const double win2 = win * win, lo2 = win2 * (1.0 - 1e-9), hi2 = win2 * (1.0 + 1e-9);
+  // fp32 band: keypoint coordinates are exact floats below 2048; a projection within window+1 of one is rounded by
+  // < 1.3e-4, so the fp32 squared distance is off by < 0.002*(window+1) near the threshold; farther away it only grows.
+  const float band = (float)(0.002 * (win + 1.0) + 1e-6 * win2);
+  const float flo = (float)win2 - band, fhi = (float)win2 + band;
   int qn = 0;  // wave-uniform queue fill
   auto flush = [&]() {
     for (int e = lane; e < qn; e += 64) {
@@ -354,21 +381,56 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom
     }
     qn = 0;
   };
-  for (int r0 = wid; r0 < nr; r0 += MATCH_WAVES) {
-    const int r = __builtin_amdgcn_readfirstlane(r0);
-    const double* X = fb.kp_xyz + (rbase + r) * 3;
-    const double u = dot4(RP, X[0], X[1], X[2], 1.0), v = dot4(RP + 4, X[0], X[1], X[2], 1.0), w = dot4(RP + 8, X[0], X[1], X[2], 1.0);
-    const double inv = 1.0 / w;  // Eigen 3.2 `v /= s` multiplies by the reciprocal
-    const double pu = u * inv, pv = v * inv;
-    for (int t0 = 0; t0 < nt; t0 += 64) {
-      const int t = t0 + lane;
+  auto bcast = [](double v, int j) {  // v_readlane of a double (j is wave-uniform)
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), j);
+    return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+  };
+  // wave `wid` owns the reference keypoints wid, wid+16, ...; 64 of them are projected at a time, one per lane
+  for (int rb = wid; rb < nr; rb += MATCH_WAVES * 64) {
+    double lpu = 0, lpv = 0;
+    {
+      const int rl = rb + MATCH_WAVES * lane;
+      if (rl < nr) {
+        const double* X = fb.kp_xyz + (rbase + rl) * 3;
+        const double u = dot4(RP, X[0], X[1], X[2], 1.0), v = dot4(RP + 4, X[0], X[1], X[2], 1.0), w = dot4(RP + 8, X[0], X[1], X[2], 1.0);
+        const double inv = 1.0 / w;  // Eigen 3.2 `v /= s` multiplies by the reciprocal
+        lpu = u * inv; lpv = v * inv;
+      }
+    }
+   for (int j = 0; j < 64; j++) {
+    const int r = __builtin_amdgcn_readfirstlane(rb + MATCH_WAVES * j);
+    if (r >= nr) break;
+    const double pu = bcast(lpu, j), pv = bcast(lpv, j);
+    const float fpu = (float)pu, fpv = (float)pv;
+    unsigned long long runs = nruns >= 64 ? ~0ull : ((1ull << nruns) - 1ull);
+    if (boxed) {
+      bool hit = false;
+      if (lane < nruns) {
+        const float4 bx = s_box[lane];
+        // distance from the projection to the box, in fp64 on exact inputs; fmax drops a NaN projection to 0 (= visit)
+        const double dx = fmax(fmax((double)bx.x - pu, pu - (double)bx.z), 0.0);
+        const double dy = fmax(fmax((double)bx.y - pv, pv - (double)bx.w), 0.0);
+        hit = !(dx * dx + dy * dy > hi2 * (1.0 + 1e-9));
+      }
+      runs = __ballot(hit);
+    }
+    while (runs) {
+      const int run = __ffsll((long long)runs) - 1;
+      runs &= runs - 1ull;
+      const int t = (run << 6) + lane;
       bool cand = false;
       if (t < nt) {
         const float2 uv = s_tuv[t];
-        const double ex = (double)uv.x - pu, ey = (double)uv.y - pv;
-        const double d2 = ex * ex + ey * ey;
-        // err.norm() < window (motion_estimate.cpp:335); sqrt only in the 1e-9 band around the threshold
-        cand = d2 < lo2 ? true : (d2 > hi2 ? false : sqrt(d2) < win);
+        const float fx = uv.x - fpu, fy = uv.y - fpv;
+        const float fd2 = fx * fx + fy * fy;
+        if (fd2 < flo) {
+          cand = true;
+        } else if (!(fd2 > fhi)) {  // rounding band or NaN: the reference's fp64 evaluation
+          const double ex = (double)uv.x - pu, ey = (double)uv.y - pv;
+          const double d2 = ex * ex + ey * ey;
+          cand = d2 < lo2 ? true : (d2 > hi2 ? false : sqrt(d2) < win);
+        }
       }
       const unsigned long long m = __ballot(cand);
       if (m) {
@@ -377,6 +439,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom
         if (qn > MATCH_QCAP - 64) flush();
       }
     }
+   }
   }
   flush();
   __syncthreads();
