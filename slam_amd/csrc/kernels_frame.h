@@ -110,7 +110,10 @@ __device__ inline int gauss_tap(F at, int n, int r) {
   return (at(o) + 4 * at(o + 1) + 7 * at(o + 2) + 4 * at(o + 3)) >> 4;
 }
 
-// grid (ceil(dw/64), ceil(dh/16), n_frames); both truncating passes fused through LDS.
+// grid (ceil(dw/64), ceil(dh/16), n_frames); both truncating passes fused through LDS.  Interior outputs are computed
+// four at a time on u16 pairs packed in 32-bit registers (a tap sum is at most 16*255, so plain integer adds and
+// multiplies never carry between the halves); the first/last output of a line takes the reference's edge formulas
+// through gauss_tap.
 __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots, int lvl) {
   const LevelGeom S = g.lv[lvl - 1], D = g.lv[lvl];
   const int slot = slots[blockIdx.z];
@@ -121,8 +124,9 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
   const int ox0 = blockIdx.x * PYR_TW, oy0 = blockIdx.y * PYR_TH;
   const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
   __shared__ __align__(16) uint8_t s_src[PYR_SROWS][PYR_SCOLS];
-  __shared__ uint8_t s_mid[PYR_SROWS][PYR_TW];
+  __shared__ __align__(16) uint16_t s_mid[PYR_SROWS][PYR_TW];
   const int tid = threadIdx.x;
+  const uint32_t M = 0x00FF00FFu;
 
   for (int i = tid; i < PYR_SROWS * (PYR_SCOLS / 4); i += 256) {
     const int r = i / (PYR_SCOLS / 4), c4 = i % (PYR_SCOLS / 4);
@@ -141,24 +145,53 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
   }
   __syncthreads();
   // pass 1: along x (source rows -> s_mid), what the reference stores transposed in pyrbuf
-  for (int i = tid; i < PYR_SROWS * PYR_TW; i += 256) {
-    const int r = i / PYR_TW, x = i % PYR_TW;
-    const int gy = sy0 + r, ox = ox0 + x;
-    int v = 0;
+  const int lastx = S.w / 2 - 1, lasty = S.h / 2 - 1;
+  for (int i = tid; i < PYR_SROWS * (PYR_TW / 4); i += 256) {
+    const int r = i / (PYR_TW / 4), x4 = (i % (PYR_TW / 4)) * 4;
+    const int gy = sy0 + r, ox = ox0 + x4;
+    uint2 out = make_uint2(0u, 0u);
     if (gy >= 0 && gy < S.h && ox < dw) {
       const uint8_t* row = s_src[r];
-      v = gauss_tap([&](int k) { return (int)row[k - sx0]; }, S.w, ox);
+      if (ox >= 1 && ox + 3 < lastx) {
+        // bytes 2*x4 .. 2*x4+15 of the staged row; output ox+j reads bytes 2*x4 + 2 + 2j .. +4
+        const uint2 a = *reinterpret_cast<const uint2*>(row + 2 * x4), c = *reinterpret_cast<const uint2*>(row + 2 * x4 + 8);
+        const uint32_t E0 = a.x & M, E1 = a.y & M, E2 = c.x & M, E3 = c.y & M;                            // even bytes, pairs
+        const uint32_t O0 = (a.x >> 8) & M, O1 = (a.y >> 8) & M, O2 = (c.x >> 8) & M;                     // odd bytes
+        const uint32_t e12 = __builtin_amdgcn_alignbit(E1, E0, 16), e34 = __builtin_amdgcn_alignbit(E2, E1, 16);
+        const uint32_t e56 = __builtin_amdgcn_alignbit(E3, E2, 16);
+        const uint32_t o12 = __builtin_amdgcn_alignbit(O1, O0, 16), o34 = __builtin_amdgcn_alignbit(O2, O1, 16);
+        out.x = ((e12 + e34 + 6u * E1 + 4u * (o12 + O1)) >> 4) & M;
+        out.y = ((e34 + e56 + 6u * E2 + 4u * (o34 + O2)) >> 4) & M;
+      } else {
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          v[j] = (ox + j < dw) ? (uint32_t)gauss_tap([&](int k) { return (int)row[k - sx0]; }, S.w, ox + j) : 0u;
+        out.x = v[0] | (v[1] << 16);
+        out.y = v[2] | (v[3] << 16);
+      }
     }
-    s_mid[r][x] = (uint8_t)v;
+    *reinterpret_cast<uint2*>(&s_mid[r][x4]) = out;
   }
   __syncthreads();
-  // pass 2: along y
-  const int x = tid & 63;
-  for (int y = tid >> 6; y < PYR_TH; y += 4) {
-    const int ox = ox0 + x, oy = oy0 + y;
+  // pass 2: along y; thread = 4 adjacent outputs of one row
+  {
+    const int y = tid >> 4, x4 = (tid & 15) * 4;
+    const int ox = ox0 + x4, oy = oy0 + y;
     if (ox < dw && oy < dh) {
-      int v = gauss_tap([&](int k) { return (int)s_mid[k - sy0][x]; }, S.h, oy);
-      dst[(size_t)oy * D.stride + ox] = (uint8_t)v;
+      uint8_t* drow = dst + (size_t)oy * D.stride + ox;
+      if (oy >= 1 && oy < lasty && ox + 3 < dw) {
+        uint2 A[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) A[k] = *reinterpret_cast<const uint2*>(&s_mid[2 * y + k][x4]);  // rows 2*oy-2 .. 2*oy+2
+        const uint32_t r01 = ((A[0].x + A[4].x + 6u * A[2].x + 4u * (A[1].x + A[3].x)) >> 4) & M;
+        const uint32_t r23 = ((A[0].y + A[4].y + 6u * A[2].y + 4u * (A[1].y + A[3].y)) >> 4) & M;
+        *reinterpret_cast<uint32_t*>(drow) = __builtin_amdgcn_perm(r23, r01, 0x06040200u);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (ox + j < dw) drow[j] = (uint8_t)gauss_tap([&](int k) { return (int)s_mid[k - sy0][x4 + j]; }, S.h, oy);
+      }
     }
   }
 }
