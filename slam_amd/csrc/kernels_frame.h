@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_ingest(FrameBufs fb, FrameGeom g, const
 #define PYR_TW 64
 #define PYR_TH 16
 #define PYR_SROWS (2 * PYR_TH + 3)   // 35
-#define PYR_SCOLS (2 * PYR_TW + 8)   // 136 bytes loaded per row, from 2*ox0-4
+#define PYR_SCOLS (2 * PYR_TW + 32)  // 160 bytes loaded per row as ten 16-byte words, from 2*ox0-16
 
 // One tap set of HorizontalGaussFilter (pyramid.cpp:67-99): output index r of a line of n samples.
 template <class F>
@@ -122,26 +122,18 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
   uint8_t* __restrict__ dst = fb.img + (size_t)slot * g.img_bytes + D.img_off;
   const int dw = S.w / 2, dh = S.h / 2;
   const int ox0 = blockIdx.x * PYR_TW, oy0 = blockIdx.y * PYR_TH;
-  const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
+  const int sx0 = 2 * ox0 - 16, sy0 = 2 * oy0 - 2;
   __shared__ __align__(16) uint8_t s_src[PYR_SROWS][PYR_SCOLS];
   __shared__ __align__(16) uint16_t s_mid[PYR_SROWS][PYR_TW];
   const int tid = threadIdx.x;
   const uint32_t M = 0x00FF00FFu;
 
-  for (int i = tid; i < PYR_SROWS * (PYR_SCOLS / 4); i += 256) {
-    const int r = i / (PYR_SCOLS / 4), c4 = i % (PYR_SCOLS / 4);
-    const int gy = sy0 + r, gx = sx0 + 4 * c4;
-    uint32_t v = 0;
-    if (gy >= 0 && gy < S.h) {
-      const uint8_t* row = src + (size_t)gy * S.stride;
-      if (gx >= 0 && gx + 3 < S.stride) {
-        v = *reinterpret_cast<const uint32_t*>(row + gx);
-      } else {
-        for (int k = 0; k < 4; k++)
-          if (gx + k >= 0 && gx + k < S.stride) v |= (uint32_t)row[gx + k] << (8 * k);
-      }
-    }
-    *reinterpret_cast<uint32_t*>(&s_src[r][4 * c4]) = v;
+  for (int i = tid; i < PYR_SROWS * (PYR_SCOLS / 16); i += 256) {
+    const int r = i / (PYR_SCOLS / 16), c16 = i % (PYR_SCOLS / 16);
+    const int gy = sy0 + r, gx = sx0 + 16 * c16;  // multiple of 16; level strides are multiples of 16
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (gy >= 0 && gy < S.h && gx >= 0 && gx < S.stride) v = *reinterpret_cast<const uint4*>(src + (size_t)gy * S.stride + gx);
+    *reinterpret_cast<uint4*>(&s_src[r][16 * c16]) = v;
   }
   __syncthreads();
   // pass 1: along x (source rows -> s_mid), what the reference stores transposed in pyrbuf
@@ -153,8 +145,9 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
     if (gy >= 0 && gy < S.h && ox < dw) {
       const uint8_t* row = s_src[r];
       if (ox >= 1 && ox + 3 < lastx) {
-        // bytes 2*x4 .. 2*x4+15 of the staged row; output ox+j reads bytes 2*x4 + 2 + 2j .. +4
-        const uint2 a = *reinterpret_cast<const uint2*>(row + 2 * x4), c = *reinterpret_cast<const uint2*>(row + 2 * x4 + 8);
+        // bytes 2*x4+12 .. 2*x4+27 of the staged row; output ox+j reads bytes 2*x4 + 14 + 2j .. +4
+        const uint32_t* rw = reinterpret_cast<const uint32_t*>(row + 2 * x4 + 12);
+        const uint2 a = make_uint2(rw[0], rw[1]), c = make_uint2(rw[2], rw[3]);
         const uint32_t E0 = a.x & M, E1 = a.y & M, E2 = c.x & M, E3 = c.y & M;                            // even bytes, pairs
         const uint32_t O0 = (a.x >> 8) & M, O1 = (a.y >> 8) & M, O2 = (c.x >> 8) & M;                     // odd bytes
         const uint32_t e12 = __builtin_amdgcn_alignbit(E1, E0, 16), e34 = __builtin_amdgcn_alignbit(E2, E1, 16);
