@@ -269,28 +269,21 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   const uint8_t* __restrict__ img = fb.img + (size_t)slot * g.img_bytes + G.img_off;
   const int TP = L.tile_pitch, SP = L.score_pitch;
 
-  // ---- stage cell + 4 px halo (index walkers avoid per-element integer division)
-  const int trows = ch + 8, tdw = TP / 4;
-  const int gx0 = cx0 - 4, gy0 = cy0 - 4;
-  const bool aligned = (gx0 & 3) == 0;
+  // ---- stage cell + 4 px halo with 16-byte loads: the tile starts at the 16-aligned column at or left of cx0-4
+  // (shx = columns between the two), rows are TP = multiple-of-16 bytes.  Index walkers avoid integer division.
+  const int trows = ch + 8, t16 = TP / 16;
+  const int gx0 = (cx0 - 4) & ~15, gy0 = cy0 - 4;
+  const int shx = cx0 - 4 - gx0;
   {
-    const int q = 256 / tdw, rr = 256 % tdw;
-    int r = tid / tdw, c4 = tid % tdw;
+    const int q = 256 / t16, rr = 256 % t16;
+    int r = tid / t16, c = tid % t16;
     while (r < trows) {
-      const int gy = gy0 + r, gx = gx0 + 4 * c4;
-      uint32_t v = 0;
-      if (gy >= 0 && gy < G.h) {
-        const uint8_t* row = img + (size_t)gy * G.stride;
-        if (aligned && gx >= 0 && gx + 3 < G.stride) {
-          v = *reinterpret_cast<const uint32_t*>(row + gx);
-        } else {
-          for (int k = 0; k < 4; k++)
-            if (gx + k >= 0 && gx + k < G.stride) v |= (uint32_t)row[gx + k] << (8 * k);
-        }
-      }
-      *reinterpret_cast<uint32_t*>(s_tile + r * TP + 4 * c4) = v;
-      c4 += rr; r += q;
-      if (c4 >= tdw) { c4 -= tdw; r++; }
+      const int gy = gy0 + r, gx = gx0 + 16 * c;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (gy >= 0 && gy < G.h && gx >= 0 && gx < G.stride) v = *reinterpret_cast<const uint4*>(img + (size_t)gy * G.stride + gx);
+      *reinterpret_cast<uint4*>(s_tile + r * TP + 16 * c) = v;
+      c += rr; r += q;
+      if (c >= t16) { c -= t16; r++; }
     }
   }
   // ---- FAST, phase A: cheap necessary test on the 4 compass ring pixels for every pixel of the cell + 1 px halo.
@@ -312,10 +305,10 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   {
     // 4 horizontally adjacent pixels per iteration: 5 aligned LDS dwords (centre, left, right, 3 rows up, 3 rows down)
     // feed two packed-u16 evaluations (even / odd bytes).  Group j of score row sy covers tile x = 4j..4j+3.
-    const int ngr = (sw + 2) / 4 + 1;
+    const int jlo = (shx + 3) >> 2, ngr = ((shx + sw + 2) >> 2) - jlo + 1;  // score column sx sits at tile x = sx + 3 + shx
     const int q = 256 / ngr, rr = 256 % ngr;
-    const int gsy0 = tid / ngr, gj0 = tid % ngr;
-    const int txlo = max(3, 7 - cx0), txhi = min(sw + 2, G.w - cx0);  // fast9Detect loop bounds, feature.cpp:3042-3043
+    const int gsy0 = tid / ngr, gj0 = jlo + tid % ngr;
+    const int txlo = max(3, 7 - cx0) + shx, txhi = min(sw + 2, G.w - cx0) + shx;  // fast9Detect loop bounds, feature.cpp:3042-3043
     const uint32_t b2 = (uint32_t)b | ((uint32_t)b << 16);
     unsigned long long mask = 0;
     int sy = gsy0, j = gj0;
@@ -338,7 +331,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
         mask |= (unsigned long long)(bits & vm & 0xFu) << (4 * k);
       }
       j += rr; sy += q;
-      if (j >= ngr) { j -= ngr; sy++; }
+      if (j >= jlo + ngr) { j -= ngr; sy++; }
     }
     // wave-level reservation
     const int mine = __popcll(mask);
@@ -355,10 +348,10 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
       while (bits) {
         const int i = __ffs(bits) - 1;
         bits &= bits - 1;
-        s_cand[base++] = (uint16_t)((sy << 8) | (4 * j + i - 3));
+        s_cand[base++] = (uint16_t)((sy << 8) | (4 * j + i - 3 - shx));
       }
       j += rr; sy += q;
-      if (j >= ngr) { j -= ngr; sy++; }
+      if (j >= jlo + ngr) { j -= ngr; sy++; }
     }
   }
   __syncthreads();
@@ -369,7 +362,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     const uint16_t v = s_cand[c];
     const int sy = v >> 8, sx = v & 255;
     int d[16];
-    fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3), TP, d);
+    fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3 + shx), TP, d);
     const int A = fast9_A(d);
     if (A > b) s_score[sy * SP + sx] = (uint8_t)A;
   }

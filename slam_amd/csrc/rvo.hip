@@ -229,7 +229,7 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
                     prm->feature_search_window, prm->min_features_for_estimate};
   // FAST workgroup LDS carve-up
   FastLds& fl = c->fl;
-  fl.tile_pitch = round_up(g.gw + 8, 4);
+  fl.tile_pitch = round_up(g.gw + 8 + 15, 16);  // the tile starts on a 16-byte boundary at or left of the halo
   fl.score_pitch = round_up(g.gw + 2, 4);
   fl.off_score = round_up(fl.tile_pitch * (g.gh + 8), 16);
   fl.off_list = fl.off_score + round_up(fl.score_pitch * (g.gh + 2), 16);
@@ -238,7 +238,7 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   fl.off_misc = fl.off_list + round_up(std::max(fl.list_cap * 4, (g.gw + 2) * (g.gh + 2) * 2 + 4), 16);
   fl.total = fl.off_misc + 64 + round_up((g.gw * g.gh + 31) / 32 * 4, 16);
   if (fl.total > 150 * 1024 || g.gw + 2 > 255 || g.gh + 2 > 255 || (g.gw + 2) * (g.gh + 2) > 64 * 256 ||
-      ((g.gw + 4) / 4 + 1) * (g.gh + 2) > 16 * 256) {  // phase A of k_fast_grid: <= 16 four-pixel groups per thread
+      ((g.gw + 7) / 4 + 1) * (g.gh + 2) > 16 * 256) {  // phase A of k_fast_grid: <= 16 four-pixel groups per thread
     g_err = "grid cell too large for LDS"; delete c; return RVO_E_UNSUPPORTED; }
 
   int rc = 0;
