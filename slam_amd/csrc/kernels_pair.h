@@ -675,29 +675,41 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
 
 // ------------------------------------------------------------------ consistency matrix
 #define CONS_TILE 1024
-// grid (ceil(mcap/256), n_pairs), 256 threads: lane = row i; columns are staged through LDS in tiles of 1024 matches
-// as fp32 (broadcast reads).  |‖ref_j-ref_i‖ - ‖tgt_j-tgt_i‖| < thr (motion_estimate.cpp:505-507) is first evaluated
-// in fp32 (absolute error < 2e-5 m for coordinates up to 65 m) and repeated in fp64 -- Eigen 3.2's
-// sqrt(x*x + (y*y + z*z)) -- only inside a 1e-4 m band around the threshold, so every decision equals the fp64 one.
+// grid (ceil(mcap/256), n_pairs), 256 threads: lane = row i of row tile I = blockIdx.x; columns are staged through
+// LDS in tiles of 1024 matches as fp32 (broadcast reads).  The matrix is symmetric, so a row tile only evaluates the
+// columns j >= 256*I: its own 256 columns directly, and for the columns of later tiles every computed 32-bit word is
+// also transposed with ballots and stored into the rows of those columns (their words < 8*(I+1) come from here).
+//
+// The test |‖ref_j-ref_i‖ - ‖tgt_j-tgt_i‖| < thr (motion_estimate.cpp:505-507) is first decided without square
+// roots in fp32: with a, b the squared distances, |sqrt a - sqrt b| < t  <=>  a+b < t^2  or  (a-b)^2 < t^2 (2(a+b) - t^2).
+// It is evaluated at t = thr -/+ band, band = EstParams::cons_band >= the worst-case fp32 error of (sqrt a - sqrt b)
+// for the coordinate range of the camera (host: 4e-6 * largest coordinate); whatever is not decided the same way at
+// both ends is repeated in fp64 exactly as the reference does it (Eigen 3.2: sqrt(x*x + (y*y + z*z))).  A NaN
+// coordinate (depth.cpp:137-147 quirk) makes the reference's comparison false; the fp32 test classifies it as false too.
 __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) {
   __shared__ float s_c[(CONS_TILE + 32) * 6];
   const int pair = blockIdx.y + pb.pair0;
   for (int k = threadIdx.x; k < (CONS_TILE + 32) * 6; k += 256) s_c[k] = 0.f;  // padding columns stay finite
   if (!pb.active[pair]) return;
   const int N = pb.n_matches[pair];
-  if (blockIdx.x * 256 >= N) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int jstart = blockIdx.x * 256;
+  if (jstart >= N) return;
+  const int lane = threadIdx.x & 63;
+  const int i = jstart + threadIdx.x;
+  const int iw0 = jstart + (threadIdx.x & ~63);  // first row of this wave
   const bool live = i < N;
+  const bool wave_live = iw0 < N;
   const size_t mb = (size_t)pair * pb.mcap;
   const int ii = live ? i : N - 1;
   const double r1x = pb.m_rxyz[(mb + ii) * 3], r1y = pb.m_rxyz[(mb + ii) * 3 + 1], r1z = pb.m_rxyz[(mb + ii) * 3 + 2];
   const double t1x = pb.m_xyz[(mb + ii) * 3], t1y = pb.m_xyz[(mb + ii) * 3 + 1], t1z = pb.m_xyz[(mb + ii) * 3 + 2];
   const float fr1x = (float)r1x, fr1y = (float)r1y, fr1z = (float)r1z, ft1x = (float)t1x, ft1y = (float)t1y, ft1z = (float)t1z;
   const double thr = ep.clique_inlier_threshold;
-  const float thr_lo = (float)(thr - 1e-4), thr_hi = (float)(thr + 1e-4);
+  const float tlo = fmaxf((float)(thr - ep.cons_band), 0.f), thi = (float)(thr + ep.cons_band);
+  const float tlo2 = tlo * tlo, thi2 = thi * thi;
+  const float lo_m = 2.f * tlo2, lo_c = -tlo2 * tlo2, hi_m = 2.f * thi2, hi_c = -thi2 * thi2;  // rhs = fma(m, a+b, c)
   uint32_t* row = pb.cbits + (mb + ii) * pb.cwords;
-  int degree = 0;
-  for (int j0 = 0; j0 < N; j0 += CONS_TILE) {
+  for (int j0 = jstart; j0 < N; j0 += CONS_TILE) {
     const int nt = min(CONS_TILE, N - j0);
     __syncthreads();
     for (int k = threadIdx.x; k < nt * 3; k += 256) {
@@ -705,6 +717,7 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
       s_c[(k / 3) * 6 + 3 + k % 3] = (float)pb.m_xyz[(mb + j0) * 3 + k];
     }
     __syncthreads();
+    if (!wave_live) continue;
     for (int w0 = 0; w0 < nt; w0 += 32) {
       uint32_t word = 0, amb = 0;
       // branch-free fp32 pass over 32 columns (columns past the tile end read stale-but-finite LDS and are masked)
@@ -712,13 +725,14 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
       for (int b = 0; b < 32; b++) {
         const float* cj = s_c + (w0 + b) * 6;
         float dx = cj[0] - fr1x, dy = cj[1] - fr1y, dz = cj[2] - fr1z;
-        const float rd = __builtin_amdgcn_sqrtf(dx * dx + (dy * dy + dz * dz));  // raw v_sqrt_f32 (1 ulp) is enough for the prefilter
+        const float a = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
         dx = cj[3] - ft1x; dy = cj[4] - ft1y; dz = cj[5] - ft1z;
-        const float td = __builtin_amdgcn_sqrtf(dx * dx + (dy * dy + dz * dz));
-        const float df = fabsf(rd - td);
-        const bool c = df < thr_lo;
-        word |= (uint32_t)c << b;
-        amb |= (uint32_t)(!c && !(df > thr_hi)) << b;  // ambiguous band or NaN
+        const float bb = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+        const float e = a - bb, apb = a + bb, lhs = e * e;
+        const bool yes = (lhs < __builtin_fmaf(lo_m, apb, lo_c)) | (apb < tlo2);
+        const bool no = !(lhs <= __builtin_fmaf(hi_m, apb, hi_c)) & !(apb <= thi2);  // also true for NaN
+        word |= (uint32_t)yes << b;
+        amb |= (uint32_t)(!yes & !no) << b;
       }
       const int jend = min(32, nt - w0);
       const uint32_t vmask = jend >= 32 ? 0xFFFFFFFFu : ((1u << jend) - 1u);
@@ -738,11 +752,25 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
       }
       const int self = i - (j0 + w0);
       if (self >= 0 && self < 32) word &= ~(1u << self);
-      degree += __popc(word);
+      if (!live) word = 0;
       if (live) row[(j0 + w0) >> 5] = word;
+      if (j0 + w0 >= jstart + 256) {
+        // transpose: lane b collects the 64-bit column (rows iw0..iw0+63) of column j0+w0+b
+        unsigned long long col = 0;
+#pragma unroll
+        for (int b = 0; b < 32; b++) {
+          const unsigned long long m = __ballot((word >> b) & 1u);
+          if (lane == b) col = m;
+        }
+        const int jc = j0 + w0 + lane;
+        if (lane < 32 && jc < N) {
+          uint32_t* crow = pb.cbits + (mb + jc) * pb.cwords + (iw0 >> 5);
+          crow[0] = (uint32_t)col;
+          if ((iw0 >> 5) + 1 < pb.cwords) crow[1] = (uint32_t)(col >> 32);
+        }
+      }
     }
   }
-  if (live) pb.m_degree[mb + i] = degree;
 }
 
 // ------------------------------------------------------------------ sort + greedy clique
@@ -770,8 +798,14 @@ __global__ __launch_bounds__(CLIQUE_WAVES * 64) void k_clique(PairBufs pb) {
     if (tid == 0) res->num_inliers = 0;
     return;
   }
-  for (int i = tid; i < N; i += CLIQUE_WAVES * 64) keys[i] = ((uint32_t)pb.m_degree[mb + i] << 16) | (uint32_t)i;
   const int nw = (N + 31) >> 5;
+  for (int i = tid; i < N; i += CLIQUE_WAVES * 64) {  // degree = row popcount (motion_estimate.cpp:509-512)
+    const uint32_t* r = pb.cbits + (mb + i) * pb.cwords;
+    int deg = 0;
+    for (int w = 0; w < nw; w++) deg += __popc(r[w]);
+    pb.m_degree[mb + i] = deg;
+    keys[i] = ((uint32_t)deg << 16) | (uint32_t)i;
+  }
   for (int w = tid; w < nw; w += CLIQUE_WAVES * 64) acc[w] = 0;
   __syncthreads();
   // std::sort(_matches, _matches+N, consistencyCompare): unstable, replayed exactly

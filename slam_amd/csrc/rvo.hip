@@ -226,7 +226,15 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   if (koff > 65535) { g_err = "more than 65535 keypoint slots per frame"; delete c; return RVO_E_UNSUPPORTED; }
   c->cam = CamParams{intr->fx, intr->fy, intr->cx, intr->cy, intr->fx};
   c->ep = EstParams{prm->inlier_max_reprojection_error, prm->clique_inlier_threshold, prm->max_mean_reprojection_error,
-                    prm->feature_search_window, prm->min_features_for_estimate};
+                    prm->feature_search_window, prm->min_features_for_estimate, 0.0};
+  {
+    // largest |coordinate| a keypoint can have: z <= 65.535 m (uint16 mm), x = z * (u/fx - cx/fx) with u in [0, W)
+    const double rx = std::max(std::fabs(g.neg_cx_div_fx), std::fabs((g.W - 1) * g.fx_inv + g.neg_cx_div_fx));
+    const double ry = std::max(std::fabs(g.neg_cy_div_fy), std::fabs((g.H - 1) * g.fy_inv + g.neg_cy_div_fy));
+    const double R = 65.535 * std::max(1.0, std::max(rx, ry));
+    // fp32 error of (sqrt a - sqrt b) is below 1.7e-6 * R (k_consistency); 4e-6 * R leaves a 2.3x margin
+    c->ep.cons_band = std::max(1e-4, 4e-6 * R);
+  }
   // FAST workgroup LDS carve-up
   FastLds& fl = c->fl;
   fl.tile_pitch = round_up(g.gw + 8 + 15, 16);  // the tile starts on a 16-byte boundary at or left of the halo

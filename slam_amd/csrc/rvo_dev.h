@@ -94,4 +94,5 @@ struct CamParams {
 struct EstParams {
   double inlier_max_reprojection_error, clique_inlier_threshold, max_mean_reprojection_error, feature_search_window;
   int min_features;
+  double cons_band;  // k_consistency: half-width of the fp32 decision band around clique_inlier_threshold (metres)
 };
