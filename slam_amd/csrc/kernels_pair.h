@@ -686,6 +686,7 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
 // for the coordinate range of the camera (host: 4e-6 * largest coordinate); whatever is not decided the same way at
 // both ends is repeated in fp64 exactly as the reference does it (Eigen 3.2: sqrt(x*x + (y*y + z*z))).  A NaN
 // coordinate (depth.cpp:137-147 quirk) makes the reference's comparison false; the fp32 test classifies it as false too.
+typedef float f2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) {
   __shared__ float s_c[(CONS_TILE + 32) * 6];
   const int pair = blockIdx.y + pb.pair0;
@@ -712,27 +713,33 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
   for (int j0 = jstart; j0 < N; j0 += CONS_TILE) {
     const int nt = min(CONS_TILE, N - j0);
     __syncthreads();
+    // LDS layout: per pair of columns (2p, 2p+1) twelve floats  rx0 rx1 ry0 ry1 rz0 rz1 tx0 tx1 ty0 ty1 tz0 tz1,
+    // so the packed-fp32 evaluation of two columns reads its operands with three 16-byte broadcasts
     for (int k = threadIdx.x; k < nt * 3; k += 256) {
-      s_c[(k / 3) * 6 + k % 3] = (float)pb.m_rxyz[(mb + j0) * 3 + k];
-      s_c[(k / 3) * 6 + 3 + k % 3] = (float)pb.m_xyz[(mb + j0) * 3 + k];
+      const int c = k / 3, ax = k % 3;
+      float* d = s_c + (c >> 1) * 12 + ax * 2 + (c & 1);
+      d[0] = (float)pb.m_rxyz[(mb + j0) * 3 + k];
+      d[6] = (float)pb.m_xyz[(mb + j0) * 3 + k];
     }
     __syncthreads();
     if (!wave_live) continue;
     for (int w0 = 0; w0 < nt; w0 += 32) {
       uint32_t word = 0, amb = 0;
       // branch-free fp32 pass over 32 columns (columns past the tile end read stale-but-finite LDS and are masked)
-#pragma unroll 8
-      for (int b = 0; b < 32; b++) {
-        const float* cj = s_c + (w0 + b) * 6;
-        float dx = cj[0] - fr1x, dy = cj[1] - fr1y, dz = cj[2] - fr1z;
-        const float a = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+#pragma unroll
+      for (int p = 0; p < 16; p++) {
+        const f2_t* cj = reinterpret_cast<const f2_t*>(s_c + ((w0 >> 1) + p) * 12);
+        f2_t dx = cj[0] - fr1x, dy = cj[1] - fr1y, dz = cj[2] - fr1z;
+        const f2_t a = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
         dx = cj[3] - ft1x; dy = cj[4] - ft1y; dz = cj[5] - ft1z;
-        const float bb = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-        const float e = a - bb, apb = a + bb, lhs = e * e;
-        const bool yes = (lhs < __builtin_fmaf(lo_m, apb, lo_c)) | (apb < tlo2);
-        const bool no = !(lhs <= __builtin_fmaf(hi_m, apb, hi_c)) & !(apb <= thi2);  // also true for NaN
-        word |= (uint32_t)yes << b;
-        amb |= (uint32_t)(!yes & !no) << b;
+        const f2_t bb = __builtin_elementwise_fma(dx, dx, __builtin_elementwise_fma(dy, dy, dz * dz));
+        const f2_t e = a - bb, apb = a + bb, lhs = e * e;
+        const f2_t rlo = __builtin_elementwise_fma(f2_t{lo_m, lo_m}, apb, f2_t{lo_c, lo_c});
+        const f2_t rhi = __builtin_elementwise_fma(f2_t{hi_m, hi_m}, apb, f2_t{hi_c, hi_c});
+        const bool yes0 = (lhs.x < rlo.x) | (apb.x < tlo2), yes1 = (lhs.y < rlo.y) | (apb.y < tlo2);
+        const bool no0 = !(lhs.x <= rhi.x) & !(apb.x <= thi2), no1 = !(lhs.y <= rhi.y) & !(apb.y <= thi2);  // also true for NaN
+        word |= (yes0 ? 1u << (2 * p) : 0u) | (yes1 ? 2u << (2 * p) : 0u);
+        amb |= ((!yes0 & !no0) ? 1u << (2 * p) : 0u) | ((!yes1 & !no1) ? 2u << (2 * p) : 0u);
       }
       const int jend = min(32, nt - w0);
       const uint32_t vmask = jend >= 32 ? 0xFFFFFFFFu : ((1u << jend) - 1u);
