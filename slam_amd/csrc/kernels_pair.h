@@ -151,6 +151,34 @@ __device__ inline void block_sum_d(double* v, double* s_red) {
   for (int i = 0; i < N; i++) v[i] = ((s_red[i * 4] + s_red[i * 4 + 1]) + s_red[i * 4 + 2]) + s_red[i * 4 + 3];
 }
 
+// Same sum for the latency-bound single-block kernels: N values per thread are parked in LDS ([N][256] doubles),
+// N*8 threads add 32 of them each (rotated start: lanes hit different banks), thread 0 adds the 8 partials.
+// Fixed order, so results are deterministic.  Result valid in thread 0 only.  s_big: N*256 + N*8 doubles.
+template <int N>
+__device__ inline void block_sum_lds(double* v, double* s_big) {
+  const int tid = threadIdx.x;
+  double* s_part = s_big + N * 256;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; i++) s_big[i * 256 + tid] = v[i];
+  __syncthreads();
+  if (tid < N * 8) {
+    const double* seg = s_big + tid * 32;
+    double s = 0;
+#pragma unroll 8
+    for (int j = 0; j < 32; j++) s += seg[(j + tid) & 31];
+    s_part[tid] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const double* q = s_part + i * 8;
+      v[i] = ((((((q[0] + q[1]) + q[2]) + q[3]) + q[4]) + q[5]) + q[6]) + q[7];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ initial rotation
 // grid (n_pairs), 256 threads, dynamic LDS = 5 * npx floats + 64 doubles.
 // mode 0: write q0 only; mode 1: also init_pose = Identity.rotate(q0) (fm.cpp:41-47).
@@ -1043,7 +1071,6 @@ struct GnShared {
   JacMats fwd, rev;
   double Pf[12], Pr[12];   // K(fx,fx)*motion and K(fx,fx)*motion^-1 for the error at the current estimate
   double Pnf[12], Pnr[12]; // same at the trial estimate
-  double red[28 * 4];
   double est[6], next[6], delta[6];
   double motion[12], nmotion[12];
   double final_sse;
@@ -1053,6 +1080,7 @@ struct GnShared {
 // grid (n_pairs), 256 threads.
 __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParams ep) {
   __shared__ GnShared S;
+  __shared__ double s_big[27 * 256 + 27 * 8];
   const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x;
   if (!pb.active[pair]) return;
   const int N = pb.n_matches[pair];
@@ -1106,7 +1134,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
     __syncthreads();
     {
       double v[1] = {err_sse(S.Pf, S.Pr)};
-      block_sum_d<1>(v, S.red);
+      block_sum_lds<1>(v, s_big);
       if (tid == 0) S.final_sse = v[0];
     }
     for (int it = 0; it < 6; it++) {
@@ -1146,7 +1174,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
           }
         }
       }
-      block_sum_d<27>(acc, S.red);
+      block_sum_lds<27>(acc, s_big);
       if (tid == 0) {
         double A[36], Ainv[36], delta[6], next[6];
         int q = 0;
@@ -1165,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
       }
       __syncthreads();
       double v[1] = {err_sse(S.Pnf, S.Pnr)};
-      block_sum_d<1>(v, S.red);
+      block_sum_lds<1>(v, s_big);
       if (tid == 0) {
         const double sse = v[0];
         if (sse > S.final_sse) {
@@ -1213,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
           for (int b = a; b < 6; b++) { acc[q] += ru[a] * ru[b]; acc[q] += rv[a] * rv[b]; q++; }
       }
     }
-    block_sum_d<21>(acc, S.red);
+    block_sum_lds<21>(acc, s_big);
     if (tid == 0) {
       double A[36], Ainv[36];
       int q = 0;
@@ -1246,7 +1274,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
       pb.m_reproj[mb + i] = e;
       v[0] += e;
     }
-    block_sum_d<1>(v, S.red);
+    block_sum_lds<1>(v, s_big);
     if (tid == 0) s_mean = v[0] / (double)S.n_inl;
     __syncthreads();
   };
@@ -1260,7 +1288,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
     for (int i = tid; i < N; i += 256)
       if (pb.m_inlier[mb + i] && pb.m_reproj[mb + i] > ep.inlier_max_reprojection_error) { pb.m_inlier[mb + i] = 0; fails++; }
     double v[1] = {(double)fails};
-    block_sum_d<1>(v, S.red);
+    block_sum_lds<1>(v, s_big);
     if (tid == 0) { S.n_inl -= (int)v[0]; res->num_reprojection_failures = (int)v[0]; }
     __syncthreads();
   }
