@@ -154,14 +154,23 @@ __device__ inline void block_sum_d(double* v, double* s_red) {
 // Same sum for the latency-bound single-block kernels: N values per thread are parked in LDS ([N][256] doubles),
 // N*8 threads add 32 of them each (rotated start: lanes hit different banks), thread 0 adds the 8 partials.
 // Fixed order, so results are deterministic.  Result valid in thread 0 only.  s_big: N*256 + N*8 doubles.
-template <int N>
+// NT = block size (multiple of 256).
+template <int N, int NT>
 __device__ inline void block_sum_lds(double* v, double* s_big) {
   const int tid = threadIdx.x;
   double* s_part = s_big + N * 256;
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < N; i++) s_big[i * 256 + tid] = v[i];
-  __syncthreads();
+  for (int q = 0; q < NT / 256; q++) {  // threads t, t+256, ... fold into slot t one after the other
+    if ((tid >> 8) == q) {
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        if (q == 0) s_big[i * 256 + (tid & 255)] = v[i];
+        else s_big[i * 256 + (tid & 255)] += v[i];
+      }
+    }
+    __syncthreads();
+  }
   if (tid < N * 8) {
     const double* seg = s_big + tid * 32;
     double s = 0;
@@ -1077,8 +1086,9 @@ struct GnShared {
   int stop, status, n_inl;
 };
 
-// grid (n_pairs), 256 threads.
-__global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParams ep) {
+#define GN_THREADS 256
+// grid (n_pairs), GN_THREADS threads: one workgroup per pair (512 or 1024 threads were measured 3-6x slower: the fp64 Jacobians spill).
+__global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, EstParams ep) {
   __shared__ GnShared S;
   __shared__ double s_big[27 * 256 + 27 * 8];
   const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x;
@@ -1098,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
 
   auto err_sse = [&](const double* Pf, const double* Pr) -> double {  // sum of squared bidirectional errors over inliers
     double s = 0;
-    for (int i = tid; i < N; i += 256) {
+    for (int i = tid; i < N; i += GN_THREADS) {
       if (!pb.m_inlier[mb + i]) continue;
       const double* t = pb.m_xyz + (mb + i) * 3;
       const double* r = pb.m_rxyz + (mb + i) * 3;
@@ -1134,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
     __syncthreads();
     {
       double v[1] = {err_sse(S.Pf, S.Pr)};
-      block_sum_lds<1>(v, s_big);
+      block_sum_lds<1, GN_THREADS>(v, s_big);
       if (tid == 0) S.final_sse = v[0];
     }
     for (int it = 0; it < 6; it++) {
@@ -1144,7 +1154,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
       double acc[27];
 #pragma unroll
       for (int k = 0; k < 27; k++) acc[k] = 0;
-      for (int i = tid; i < N; i += 256) {
+      for (int i = tid; i < N; i += GN_THREADS) {
         if (!pb.m_inlier[mb + i]) continue;
 #pragma unroll
         for (int dir = 0; dir < 2; dir++) {
@@ -1174,7 +1184,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
           }
         }
       }
-      block_sum_lds<27>(acc, s_big);
+      block_sum_lds<27, GN_THREADS>(acc, s_big);
       if (tid == 0) {
         double A[36], Ainv[36], delta[6], next[6];
         int q = 0;
@@ -1193,7 +1203,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
       }
       __syncthreads();
       double v[1] = {err_sse(S.Pnf, S.Pnr)};
-      block_sum_lds<1>(v, s_big);
+      block_sum_lds<1, GN_THREADS>(v, s_big);
       if (tid == 0) {
         const double sse = v[0];
         if (sse > S.final_sse) {
@@ -1218,7 +1228,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
     double acc[21];
 #pragma unroll
     for (int k = 0; k < 21; k++) acc[k] = 0;
-    for (int i = tid; i < N; i += 256) {
+    for (int i = tid; i < N; i += GN_THREADS) {
       if (!pb.m_inlier[mb + i]) continue;
 #pragma unroll
       for (int dir = 0; dir < 2; dir++) {
@@ -1241,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
           for (int b = a; b < 6; b++) { acc[q] += ru[a] * ru[b]; acc[q] += rv[a] * rv[b]; q++; }
       }
     }
-    block_sum_lds<21>(acc, s_big);
+    block_sum_lds<21, GN_THREADS>(acc, s_big);
     if (tid == 0) {
       double A[36], Ainv[36];
       int q = 0;
@@ -1265,7 +1275,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
     }
     __syncthreads();
     double v[1] = {0};
-    for (int i = tid; i < N; i += 256) {
+    for (int i = tid; i < N; i += GN_THREADS) {
       if (!pb.m_inlier[mb + i]) continue;
       const double* t = pb.m_xyz + (mb + i) * 3;
       const double h0 = dot4(S.Pnf, t[0], t[1], t[2], 1.0), h1 = dot4(S.Pnf + 4, t[0], t[1], t[2], 1.0), h2 = dot4(S.Pnf + 8, t[0], t[1], t[2], 1.0);
@@ -1274,7 +1284,7 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
       pb.m_reproj[mb + i] = e;
       v[0] += e;
     }
-    block_sum_lds<1>(v, s_big);
+    block_sum_lds<1, GN_THREADS>(v, s_big);
     if (tid == 0) s_mean = v[0] / (double)S.n_inl;
     __syncthreads();
   };
@@ -1285,10 +1295,10 @@ __global__ __launch_bounds__(256) void k_gn(PairBufs pb, CamParams cam, EstParam
   {
     __syncthreads();
     int fails = 0;
-    for (int i = tid; i < N; i += 256)
+    for (int i = tid; i < N; i += GN_THREADS)
       if (pb.m_inlier[mb + i] && pb.m_reproj[mb + i] > ep.inlier_max_reprojection_error) { pb.m_inlier[mb + i] = 0; fails++; }
     double v[1] = {(double)fails};
-    block_sum_lds<1>(v, s_big);
+    block_sum_lds<1, GN_THREADS>(v, s_big);
     if (tid == 0) { S.n_inl -= (int)v[0]; res->num_reprojection_failures = (int)v[0]; }
     __syncthreads();
   }
