@@ -529,10 +529,13 @@ __device__ inline int norm_px(int v, int mean) {  // Descriptor::Normalized, fea
   return v;
 }
 
-// sum over the 16 lanes of a match group
+// sum over the 16 lanes of a match group (= one DPP row): xor-1 and xor-2 butterflies as quad permutes, then the
+// half-row and row mirrors; every lane ends with the total.  No LDS-crossbar shuffles on the iteration's critical path.
 __device__ inline int group16_sum(int v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
   return v;
 }
 
@@ -568,9 +571,13 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
   int toff[REFINE_TAPS];
 #pragma unroll
   for (int m = 0; m < REFINE_TAPS; m++) toff[m] = desc_off(gl + REFINE_GROUP * m, S);
-  auto interp = [&](const Wts& w, int o) -> int {
+  // the four bilinear neighbours of a tap; the first three are also the taps of the target gradient at the same
+  // integer position (motion_estimate.cpp:800-815), so an accepted step needs no further loads for the next one
+  struct Nb { int p00, p01, p10; };
+  auto interp = [&](const Wts& w, int o, Nb& nb) -> int {
     const int k = w.base + o;
-    const float f = ((w.wa * (float)tg[k] + w.wb * (float)tg[k + 1]) + w.wc * (float)tg[k + S]) + w.wd * (float)tg[k + S + 1];
+    nb.p00 = tg[k]; nb.p01 = tg[k + 1]; nb.p10 = tg[k + S];
+    const float f = ((w.wa * (float)nb.p00 + w.wb * (float)nb.p01) + w.wc * (float)nb.p10) + w.wd * (float)tg[k + S + 1];
     return (int)f;
   };
   const int rbase = kp_y(rkp) * S + kp_x(rkp);
@@ -578,6 +585,7 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
   float tx = tu, ty = tv;
   Wts wt = make_wts(tx, ty, S);
   int rraw[REFINE_TAPS], rdx[REFINE_TAPS], rdy[REFINE_TAPS], traw[REFINE_TAPS];
+  Nb tnb[REFINE_TAPS];
   int rsum = 0, tsum = 0;
 #pragma unroll
   for (int m = 0; m < REFINE_TAPS; m++) {
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     rraw[m] = rg[kr];
     rdx[m] = rg[kr + 1] - rraw[m];
     rdy[m] = rg[kr + S] - rraw[m];
-    traw[m] = interp(wt, toff[m]);
+    traw[m] = interp(wt, toff[m], tnb[m]);
     rsum += rraw[m];
     tsum += traw[m];
   }
@@ -602,14 +610,11 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
   final_sse = group16_sum(final_sse);
   const int min_xy = RVO_WIN, max_x = G.w - RVO_WIN - 2, max_y = G.h - RVO_WIN - 2;  // pyramid.cpp:123-126
   for (int it = 0; it < 6; it++) {
-    const int tc = ((int)ty) * S + (int)tx;
     int S00 = 0, S01 = 0, S11 = 0, gxs = 0, gys = 0;
 #pragma unroll
     for (int m = 0; m < REFINE_TAPS; m++) {
-      const int kt = tc + toff[m];
-      const int t0 = tg[kt];
-      const int mx = rdx[m] + (tg[kt + 1] - t0);
-      const int my = rdy[m] + (tg[kt + S] - t0);
+      const int mx = rdx[m] + (tnb[m].p01 - tnb[m].p00);
+      const int my = rdy[m] + (tnb[m].p10 - tnb[m].p00);
       const int e = norm_px(traw[m], tmean) - rn[m];
       S00 += mx * mx; S01 += mx * my; S11 += my * my; gxs += mx * e; gys += my * e;
     }
@@ -625,9 +630,10 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     if (!(ntx >= (float)min_xy && ntx <= (float)max_x && nty >= (float)min_xy && nty <= (float)max_y)) break;
     const Wts wn = make_wts(ntx, nty, S);
     int nraw[REFINE_TAPS];
+    Nb nnb[REFINE_TAPS];
     int nsum = 0;
 #pragma unroll
-    for (int m = 0; m < REFINE_TAPS; m++) { nraw[m] = interp(wn, toff[m]); nsum += nraw[m]; }
+    for (int m = 0; m < REFINE_TAPS; m++) { nraw[m] = interp(wn, toff[m], nnb[m]); nsum += nraw[m]; }
     const int nmean = group16_sum(nsum) / RVO_DESC_LEN;
     int sse = 0;
 #pragma unroll
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     if (sse < final_sse) {
       tx = ntx; ty = nty; final_sse = sse; tmean = nmean;
 #pragma unroll
-      for (int m = 0; m < REFINE_TAPS; m++) traw[m] = nraw[m];
+      for (int m = 0; m < REFINE_TAPS; m++) { traw[m] = nraw[m]; tnb[m] = nnb[m]; }
     } else break;
     if (fabs(dxs) < 0.1 && fabs(dys) < 0.1) break;
   }
