@@ -92,15 +92,19 @@ def main():
     from slam_amd import synth
     from slam_amd.api import Context, default_params
 
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        # gloo carries the control plane (barriers, the max-over-ranks clock); nccl (= RCCL over xGMI) carries the
+        # one data collective of the path, the final trajectory gather
+        dist.init_process_group("cpu:gloo,cuda:nccl")
+    dev = torch.device("cuda", dev_index)
     d_gray = torch.from_numpy(gray).to(dev)
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
 
     intr = synth.default_intrinsics(640, 480)
-    ctx = Context(intr, default_params(frame_matcher=True), max_frames=2 * n_pairs, max_pairs=n_pairs, device=local_rank)
+    ctx = Context(intr, default_params(frame_matcher=True), max_frames=2 * n_pairs, max_pairs=n_pairs, device=dev_index)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     slots = np.arange(2 * n_pairs, dtype=np.int32)
     refs, tgts = slots[0::2].copy(), slots[1::2].copy()
@@ -116,7 +120,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.all_reduce(torch.zeros(1))  # CPU tensor -> gloo
 
     if not os.environ.get("RVO_BENCH_NOPROF"):
         ctx.profile_enable(True)  # HIP events around every launch, on the stream the kernels run on
@@ -131,20 +135,26 @@ def main():
     prof = ctx.profile_read()
     ctx.profile_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # results + final trajectory gather (RCCL all_gather of the per-pair 3x4 poses and status)
     res = ctx.pair_results(n_pairs)
     gather_ms = None
+    gather_backend = None
     if world > 1:
         from slam_amd.dist import gather_trajectories
         local = np.stack([np.concatenate([r["pose"].reshape(12), [r["status"], r["num_inliers"]]]) for r in res])
         torch.cuda.synchronize()
-        dist.barrier()
+        barrier()
         g0 = time.perf_counter()
-        allp = gather_trajectories(local, dev)
+        try:
+            allp = gather_trajectories(local, dev)
+            gather_backend = "nccl"
+        except Exception as e:  # e.g. ranks sharing one GPU in a rehearsal: RCCL refuses duplicate devices
+            gather_backend = f"gloo (nccl gather failed: {type(e).__name__})"
+            allp = gather_trajectories(local, None)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         assert allp.shape == (world * n_pairs, 14)
@@ -204,7 +214,7 @@ def main():
                                        note="SURVEY 8(d) B_pair at the measured K and N, per GPU"),
                     cpu_baseline=cpu, kernels=kernels, stats=stats,
                     check=dict(pairs_success=ok, max_abs_pose_err_vs_truth=float(err)),
-                    gather_ms=gather_ms)
+                    gather_ms=gather_ms, gather_backend=gather_backend)
         print(json.dumps(line))
     ctx.close()
     if world > 1:
