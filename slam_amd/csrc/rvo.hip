@@ -55,11 +55,10 @@ struct rvo_ctx {
   rvo_stream_result* d_stream_res = nullptr;
   int n_streams = 0;
   int32_t* d_sslots = nullptr;  // [2n]: current slot (-1 = warm-up skip), FAST threshold (device-written)
-  int32_t* d_pargs = nullptr;
   double* d_pinit = nullptr;
   int lds_rot = 0, lds_match = 0, lds_clique = 0;
   // pinned ring for small host->device argument arrays (slot lists, thresholds, initial poses)
-  static const int kRing = 8;
+  static const int kRing = 32;
   uint8_t* h_ring = nullptr;
   size_t ring_bytes = 0;
   hipEvent_t ring_ev[kRing] = {};
