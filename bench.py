@@ -111,8 +111,8 @@ def main():
     thr = ctx.params.fast_init_threshold
 
     def step():
-        ctx.prepare_frames_dev(d_gray.data_ptr(), d_depth.data_ptr(), thr, slots)
-        ctx.match_pairs_async(refs, tgts)
+        # FrameMatcher::Match for the whole batch: Frame::Prepare of both frames + EstimateMotion of every pair
+        ctx.match_frames_dev(d_gray.data_ptr(), d_depth.data_ptr(), thr, slots)
 
     for _ in range(a.warmup):
         step()

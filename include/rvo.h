@@ -130,6 +130,15 @@ int rvo_match_pairs(rvo_ctx* ctx, int n, const int32_t* ref_slots, const int32_t
                     rvo_pair_result* out);
 int rvo_match_pairs_async(rvo_ctx* ctx, int n, const int32_t* ref_slots, const int32_t* tgt_slots,
                           const double* init_pose);
+
+/* FrameMatcher::Match (rgbdvo/fm.cpp:32-58) end to end for n independent pairs whose images are already in device
+ * memory: frames 2i (reference) and 2i+1 (target) of gray_dev/depth_dev go through Frame::Prepare
+ * (rgbdvo/frame.cpp:38-149) into slots[2i], slots[2i+1] with FAST thresholds fast_thr[2i], fast_thr[2i+1], then pair
+ * work area i estimates slots[2i] -> slots[2i+1] exactly as rvo_match_pairs_async does.  The batch is cut into
+ * chunks that run the whole frame+pair pipeline on separate HIP streams, so the latency-bound pair stages of one
+ * chunk overlap the throughput-bound frame stages of another.  Enqueues only; results via rvo_get_pair_results. */
+int rvo_match_frames_dev(rvo_ctx* ctx, int n, const uint8_t* gray_dev, const uint16_t* depth_dev, const int32_t* fast_thr,
+                         const int32_t* slots, const double* init_pose);
 int rvo_get_pair_results(rvo_ctx* ctx, int n, rvo_pair_result* out);
 /* EstimateInitialRotation alone: q[n][4] = (w,x,y,z) */
 int rvo_initial_rotation(rvo_ctx* ctx, int n, const int32_t* prev_slots, const int32_t* cur_slots, double* q_wxyz);

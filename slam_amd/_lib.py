@@ -47,7 +47,7 @@ class StreamResult(C.Structure):
 SYMBOLS = [
     "rvo_default_vo_params", "rvo_default_fm_params", "rvo_create", "rvo_destroy", "rvo_last_error",
     "rvo_set_stream", "rvo_sync", "rvo_prepare_frames", "rvo_prepare_frames_dev", "rvo_match_pairs",
-    "rvo_match_pairs_async", "rvo_get_pair_results", "rvo_initial_rotation", "rvo_streams_reset",
+    "rvo_match_pairs_async", "rvo_match_frames_dev", "rvo_get_pair_results", "rvo_initial_rotation", "rvo_streams_reset",
     "rvo_stream_step", "rvo_stream_step_dev", "rvo_get_stream_results", "rvo_stream_results_dev",
     "rvo_get_stream_slots",
     "rvo_get_level_info", "rvo_get_level_image", "rvo_get_grid_keypoints", "rvo_get_keypoints",
@@ -77,6 +77,7 @@ def load():
     L.rvo_prepare_frames_dev.argtypes = [vp, ip, vp, vp, vp, vp]
     L.rvo_match_pairs.argtypes = [vp, ip, vp, vp, vp, vp]
     L.rvo_match_pairs_async.argtypes = [vp, ip, vp, vp, vp]
+    L.rvo_match_frames_dev.argtypes = [vp, ip, vp, vp, vp, vp, vp]
     L.rvo_get_pair_results.argtypes = [vp, ip, vp]
     L.rvo_initial_rotation.argtypes = [vp, ip, vp, vp, vp]
     L.rvo_streams_reset.argtypes = [vp, ip]

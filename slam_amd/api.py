@@ -130,6 +130,14 @@ class Context:
         ip = None if init_pose is None else np.ascontiguousarray(init_pose, np.float64).reshape(n, 12)
         self._chk(self.L.rvo_match_pairs_async(self.h, n, _ptr(ref_slots), _ptr(tgt_slots), _ptr(ip)))
 
+    def match_frames_dev(self, gray_ptr, depth_ptr, fast_thr, slots, init_pose=None):
+        """FrameMatcher::Match for len(slots)/2 pairs of device-resident images (frames 2i, 2i+1 -> pair i); async."""
+        slots = _i32(slots)
+        n = len(slots) // 2
+        thr = _i32(np.broadcast_to(np.asarray(fast_thr, np.int32), (2 * n,)))
+        ip = None if init_pose is None else np.ascontiguousarray(init_pose, np.float64).reshape(n, 12)
+        self._chk(self.L.rvo_match_frames_dev(self.h, n, C.c_void_p(gray_ptr), C.c_void_p(depth_ptr), _ptr(thr), _ptr(slots), _ptr(ip)))
+
     def pair_results(self, n):
         out = (PairResult * n)()
         self._chk(self.L.rvo_get_pair_results(self.h, n, out))

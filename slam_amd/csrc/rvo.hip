@@ -342,28 +342,34 @@ static int ensure_stage(rvo_ctx* c, int n) {
   return RVO_OK;
 }
 
-static int launch_ingest(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots) {
+static int launch_ingest_on(rvo_ctx* c, hipStream_t st, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots) {
   const FrameGeom& g = c->g;
   const bool vec = (g.W % 16 == 0) && (((size_t)g.Wd * g.Hd) % 8 == 0) && (((uintptr_t)gray & 15) == 0) && (((uintptr_t)depth & 15) == 0);
-  if (vec) LAUNCH(c, "ingest", k_ingest<true>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots);
-  else LAUNCH(c, "ingest", k_ingest<false>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots);
+  if (vec) LAUNCH_ON(c, st, "ingest", k_ingest<true>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots);
+  else LAUNCH_ON(c, st, "ingest", k_ingest<false>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots);
   return RVO_OK;
+}
+static int launch_ingest(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots) {
+  return launch_ingest_on(c, c->stream, n, gray, depth, d_slots);
 }
 
 // ---------------------------------------------------------------- PrepareFrame
-// enqueue the frame kernels for n frames whose slots/thresholds are at d_slots/d_thr (device)
-static int enqueue_prepare(rvo_ctx* c, int n, const int32_t* d_slots, const int32_t* d_thr) {
+// enqueue the frame kernels on stream `st` for n frames whose slots/thresholds are at d_slots/d_thr (device)
+static int enqueue_prepare_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots, const int32_t* d_thr) {
   const FrameGeom& g = c->g;
   for (int l = 1; l < g.levels; l++) {
     const int dw = g.lv[l - 1].w / 2, dh = g.lv[l - 1].h / 2;
     dim3 grid((dw + PYR_TW - 1) / PYR_TW, (dh + PYR_TH - 1) / PYR_TH, n);
-    LAUNCH(c, "pyr_down", k_pyr_down, grid, dim3(256), 0, c->fb, g, d_slots, l);
+    LAUNCH_ON(c, st, "pyr_down", k_pyr_down, grid, dim3(256), 0, c->fb, g, d_slots, l);
   }
-  LAUNCH(c, "fast_grid", k_fast_grid, dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
-  LAUNCH(c, "build_keypoints", k_build_keypoints, dim3(g.levels, n), dim3(256), 0, c->fb, g, d_slots);
-  LAUNCH(c, "descriptors", k_descriptors, dim3((g.kp_total + DESC_PER_BLOCK - 1) / DESC_PER_BLOCK, n), dim3(256), 0, c->fb, g, d_slots);
+  LAUNCH_ON(c, st, "fast_grid", k_fast_grid, dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
+  LAUNCH_ON(c, st, "build_keypoints", k_build_keypoints, dim3(g.levels, n), dim3(256), 0, c->fb, g, d_slots);
+  LAUNCH_ON(c, st, "descriptors", k_descriptors, dim3((g.kp_total + DESC_PER_BLOCK - 1) / DESC_PER_BLOCK, n), dim3(256), 0, c->fb, g, d_slots);
   HIPCHK(hipGetLastError());
   return RVO_OK;
+}
+static int enqueue_prepare(rvo_ctx* c, int n, const int32_t* d_slots, const int32_t* d_thr) {
+  return enqueue_prepare_on(c, c->stream, n, d_slots, d_thr);
 }
 
 int rvo_prepare_frames_dev(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* thr, const int32_t* slots) {

@@ -142,3 +142,40 @@ def test_large_frames_config4(scene):
     assert ro["num_matches"] > 1500
     compare_pair(ctx, orc, 0, rg, ro)
     ctx.close()
+
+
+def test_match_frames_dev_equals_two_call_path(scene, intr640):
+    """rvo_match_frames_dev (fused, chunked over HIP streams) == rvo_prepare_frames_dev + rvo_match_pairs, bit for bit,
+    and pair 0 / the last pair also equal the oracle."""
+    import torch
+    from oracle.pyoracle import Oracle, default_params as odef
+    from slam_amd.api import Context, default_params
+    n = 70  # > 64 so that the batch is cut into two chunks
+    pairs = [synth.make_pair(300 + i, intr640, scene, invalid_frac=0.05 * (i % 3)) for i in range(6)]
+    gray = np.stack([pairs[i % 6][j] for i in range(n) for j in (0, 2)])
+    depth = np.stack([pairs[i % 6][j] for i in range(n) for j in (1, 3)])
+    dg = torch.from_numpy(gray).cuda()
+    dd = torch.from_numpy(depth.view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    slots = np.arange(2 * n, dtype=np.int32)
+    a = Context(intr640, default_params(frame_matcher=True), max_frames=2 * n, max_pairs=n)
+    b = Context(intr640, default_params(frame_matcher=True), max_frames=2 * n, max_pairs=n)
+    a.prepare_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, slots)
+    ra = a.match_pairs(slots[0::2], slots[1::2])
+    b.match_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, slots)
+    rb = b.pair_results(n)
+    for i in range(n):
+        assert ra[i]["status"] == rb[i]["status"] and ra[i]["num_matches"] == rb[i]["num_matches"]
+        assert ra[i]["num_inliers"] == rb[i]["num_inliers"]
+        assert np.array_equal(ra[i]["pose"], rb[i]["pose"]) and np.array_equal(ra[i]["cov"], rb[i]["cov"])
+        if i in (0, 37, n - 1):
+            ia, da = a.matches(i, ra[i]["num_matches"])
+            ib, db = b.matches(i, rb[i]["num_matches"])
+            assert np.array_equal(ia, ib) and np.array_equal(da, db, equal_nan=True)
+    orc = Oracle(intr640, odef(frame_matcher=True))
+    for i in (0, n - 1):
+        orc.prepare(0, gray[2 * i], depth[2 * i], 20)
+        orc.prepare(1, gray[2 * i + 1], depth[2 * i + 1], 20)
+        compare_pair(b, orc, i, rb[i], orc.match_pair(0, 1))
+    a.close()
+    b.close()
