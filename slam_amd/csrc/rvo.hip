@@ -62,6 +62,7 @@ struct rvo_ctx {
   uint8_t* h_ring = nullptr;
   size_t ring_bytes = 0;
   hipEvent_t ring_ev[kRing] = {};
+  hipEvent_t ev_pyr[2] = {}, ev_rot[2] = {};  // rvo_match_frames_dev: initial rotation on a side stream
   int ring_pos = 0;
   // auxiliary streams: chunks of a pair batch are pipelined against each other (fork/join around the main stream)
   static const int kAux = 3;
@@ -259,6 +260,10 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
     HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
   }
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  for (int i = 0; i < 2; i++) {
+    HIPCHK(hipEventCreateWithFlags(&c->ev_pyr[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_rot[i], hipEventDisableTiming));
+  }
   if (const char* e = getenv("RVO_PAIR_CHUNKS")) c->pair_chunks = std::max(1, std::min(rvo_ctx::kAux + 1, atoi(e)));
   FrameBufs& fb = c->fb;
   const size_t F = max_frames;
@@ -314,6 +319,10 @@ void rvo_destroy(rvo_ctx* c) {
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (int i = 0; i < 2; i++) {
+    if (c->ev_pyr[i]) (void)hipEventDestroy(c->ev_pyr[i]);
+    if (c->ev_rot[i]) (void)hipEventDestroy(c->ev_rot[i]);
+  }
   delete c;
 }
 
@@ -355,18 +364,26 @@ static int launch_ingest(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t*
 
 // ---------------------------------------------------------------- PrepareFrame
 // enqueue the frame kernels on stream `st` for n frames whose slots/thresholds are at d_slots/d_thr (device)
-static int enqueue_prepare_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots, const int32_t* d_thr) {
+static int enqueue_pyramid_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots) {
   const FrameGeom& g = c->g;
   for (int l = 1; l < g.levels; l++) {
     const int dw = g.lv[l - 1].w / 2, dh = g.lv[l - 1].h / 2;
     dim3 grid((dw + PYR_TW - 1) / PYR_TW, (dh + PYR_TH - 1) / PYR_TH, n);
     LAUNCH_ON(c, st, "pyr_down", k_pyr_down, grid, dim3(256), 0, c->fb, g, d_slots, l);
   }
+  return RVO_OK;
+}
+static int enqueue_features_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots, const int32_t* d_thr) {
+  const FrameGeom& g = c->g;
   LAUNCH_ON(c, st, "fast_grid", k_fast_grid, dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
   LAUNCH_ON(c, st, "build_keypoints", k_build_keypoints, dim3(g.levels, n), dim3(256), 0, c->fb, g, d_slots);
   LAUNCH_ON(c, st, "descriptors", k_descriptors, dim3((g.kp_total + DESC_PER_BLOCK - 1) / DESC_PER_BLOCK, n), dim3(256), 0, c->fb, g, d_slots);
   HIPCHK(hipGetLastError());
   return RVO_OK;
+}
+static int enqueue_prepare_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots, const int32_t* d_thr) {
+  enqueue_pyramid_on(c, st, n, d_slots);
+  return enqueue_features_on(c, st, n, d_slots, d_thr);
 }
 static int enqueue_prepare(rvo_ctx* c, int n, const int32_t* d_slots, const int32_t* d_thr) {
   return enqueue_prepare_on(c, c->stream, n, d_slots, d_thr);
