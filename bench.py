@@ -170,15 +170,30 @@ def main():
         total_pairs = world * n_pairs * a.steps
         value = total_pairs / dt
         geom = dict(W=640, H=480, levels=3, total_buckets=64, max_per=25)
-        B = algorithmic_bytes(geom, stats)
+        B = algorithmic_bytes(geom, stats)  # per launch if the whole batch is one launch
+        for k in list(B):  # the batch runs as stream chunks: scale to what ONE launch of the kernel processes
+            if k in prof:
+                base = (geom["levels"] - 1) if k == "pyr_down" else 1
+                B[k] = B[k] / max(1.0, prof[k]["calls"] / (a.steps * base))
         dom = max(prof, key=lambda k: prof[k]["total_ms"]) if prof else None
         roof = None
         if dom and dom in B:
             avg_s = prof[dom]["total_ms"] / prof[dom]["calls"] * 1e-3
             ach = B[dom] / avg_s
+            # HBM traffic per launch: not measurable from inside this process; taken from the committed rocprofv3
+            # --pmc passes of this same command (profiles/r01_pmc_traffic.json), valid for the default launch shape
+            traffic, traffic_src = None, None
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(tp) and n_pairs == 256 and not os.environ.get("RVO_PAIR_CHUNKS"):
+                tj = json.load(open(tp))
+                if dom in tj["kernels"]:
+                    traffic = tj["kernels"][dom]["traffic_bytes"]
+                    traffic_src = "profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, separate --pmc passes"
             roof = dict(bound="hbm", kernel=dom, achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=ach / HBM_PEAK, traffic=None, avg_launch_ms=avg_s * 1e3,
-                        algorithmic_bytes_per_launch=B[dom])
+                        frac=ach / HBM_PEAK, traffic=traffic, traffic_source=traffic_src, avg_launch_ms=avg_s * 1e3,
+                        algorithmic_bytes_per_launch=B[dom],
+                        note="launch = one chunk (half of the batch) when the batch runs as two stream chunks; "
+                             "the kernel is VALU-bound, not HBM-bound (DESIGN.md section 5)")
         kernels = {k: dict(avg_ms=v["total_ms"] / v["calls"], calls=v["calls"],
                            GBps=(B[k] / (v["total_ms"] / v["calls"] * 1e-3) / 1e9) if k in B else None)
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
