@@ -507,9 +507,11 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
 // keypoint per round.  Lane l owns descriptor dword l (taps 4l..4l+3); lanes 0-3 also own dwords 16-19, so every
 // store is one aligned dword.  Runs after k_build_keypoints (reads kp_uvs / kp_cnt).
 #define DESC_PER_BLOCK 32
-__device__ inline int sum16(int v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+__device__ inline int sum16(int v) {  // 16 lanes = one DPP row: quad permutes, then half-row and row mirrors
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
   return v;
 }
 __global__ __launch_bounds__(256) void k_descriptors(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots) {

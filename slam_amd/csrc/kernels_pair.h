@@ -547,18 +547,22 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
   const int pair = blockIdx.y + pb.pair0;
   if (!pb.active[pair]) return;
   const int gl = threadIdx.x & (REFINE_GROUP - 1);
-  const int i = blockIdx.x * (256 / REFINE_GROUP) + (threadIdx.x / REFINE_GROUP);
+  const int i_grp = blockIdx.x * (256 / REFINE_GROUP) + (threadIdx.x / REFINE_GROUP);
   int off[RVO_MAX_LEVELS + 1];
   off[0] = 0;
   for (int l = 0; l < g.levels; l++) off[l + 1] = off[l] + pb.lm_cnt[pair * RVO_MAX_LEVELS + l];
   const int N = off[g.levels];
-  if (i == 0 && gl == 0) pb.n_matches[pair] = N;
-  if (i >= N) return;
+  if (i_grp == 0 && gl == 0) pb.n_matches[pair] = N;
+  const int rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
+  // per match of this workgroup: the refined position handed to the finishing lanes
+  __shared__ float s_tx[256 / REFINE_GROUP], s_ty[256 / REFINE_GROUP];
+  __shared__ int s_r[256 / REFINE_GROUP], s_t[256 / REFINE_GROUP];
+  if (i_grp < N) {
+  const int i = i_grp;
   int lvl = 0;
   for (int l = 1; l < g.levels; l++) if (i >= off[l]) lvl = l;
   const int j = i - off[lvl];
   const LevelGeom G = g.lv[lvl];
-  const int rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
   const int r = pb.lm_ref[(size_t)pair * g.kp_total + G.kp_off + j];
   const int t = pb.lm_tgt[(size_t)pair * g.kp_total + G.kp_off + j];
   const size_t rk = (size_t)rs * g.kp_total + G.kp_off + r, tk = (size_t)ts * g.kp_total + G.kp_off + t;
@@ -649,9 +653,25 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     } else break;
     if (fabs(dxs) < 0.1 && fabs(dys) < 0.1) break;
   }
-  if (gl != 0) return;  // one lane finishes the record
-
-  // ---- gating + refined record, motion_estimate.cpp:360-376
+  if (gl == 0) {
+    const int q = threadIdx.x / REFINE_GROUP;
+    s_tx[q] = tx; s_ty[q] = ty; s_r[q] = r; s_t[q] = t;
+  }
+  }
+  __syncthreads();
+  // ---- gating + refined record, motion_estimate.cpp:360-376: lanes 0..15 of the workgroup finish one match each, so
+  // the fp64 lookups below are issued by one wave instead of once per 16-lane group in all four
+  if (threadIdx.x >= 256 / REFINE_GROUP) return;
+  const int i = blockIdx.x * (256 / REFINE_GROUP) + threadIdx.x;
+  if (i >= N) return;
+  int lvl = 0;
+  for (int l = 1; l < g.levels; l++) if (i >= off[l]) lvl = l;
+  const LevelGeom G = g.lv[lvl];
+  const int r = s_r[threadIdx.x], t = s_t[threadIdx.x];
+  const float tx = s_tx[threadIdx.x], ty = s_ty[threadIdx.x];
+  const size_t rk = (size_t)rs * g.kp_total + G.kp_off + r, tk = (size_t)ts * g.kp_total + G.kp_off + t;
+  const uint32_t tkp = fb.kp_uvs[tk];
+  const float tu = (float)kp_x(tkp), tv = (float)kp_y(tkp);
   const double ddx = (double)tu - (double)tx, ddy = (double)tv - (double)ty;
   const double dsn = sqrt(ddx * ddx + ddy * ddy);
   float2 ouv = make_float2(tu, tv);
