@@ -139,6 +139,15 @@ int rvo_match_pairs_async(rvo_ctx* ctx, int n, const int32_t* ref_slots, const i
  * chunk overlap the throughput-bound frame stages of another.  Enqueues only; results via rvo_get_pair_results. */
 int rvo_match_frames_dev(rvo_ctx* ctx, int n, const uint8_t* gray_dev, const uint16_t* depth_dev, const int32_t* fast_thr,
                          const int32_t* slots, const double* init_pose);
+
+/* Front-of-path conversions of the reference's callers, on device memory:
+ * ConvertBGR2Gray (helper.cpp:55-64, called at hand_held_demo.cpp:248, pose_graph.cpp:101,128) for n frames of the
+ * context's width x height: gray = (u8)(0.114*B + 0.587*G + 0.299*R) in fp64; and DepthToPointCloud::operator()
+ * (helper.cpp:30-53) for n depth images of depth_width x depth_height: x_to_z = 2*tan(hfov/2), y_to_z = 2*tan(vfov/2)
+ * (helper.hpp:32-36); cloud = n * Wd*Hd * 3 floats.  Both enqueue on the context's stream and return. */
+int rvo_bgr_to_gray_dev(rvo_ctx* ctx, int n, const uint8_t* bgr_dev, uint8_t* gray_dev);
+int rvo_depth_to_point_cloud_dev(rvo_ctx* ctx, int n, const uint16_t* depth_dev, double x_to_z, double y_to_z,
+                                 float* cloud_dev);
 int rvo_get_pair_results(rvo_ctx* ctx, int n, rvo_pair_result* out);
 /* EstimateInitialRotation alone: q[n][4] = (w,x,y,z) */
 int rvo_initial_rotation(rvo_ctx* ctx, int n, const int32_t* prev_slots, const int32_t* cur_slots, double* q_wxyz);

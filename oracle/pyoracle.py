@@ -77,6 +77,27 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def bgr_to_gray(bgr: np.ndarray) -> np.ndarray:
+    """ConvertBGR2Gray, /root/reference/helper.cpp:55-64.  bgr: [..., 3] u8 -> [...] u8"""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    out = np.empty(bgr.shape[:-1], np.uint8)
+    L = lib()
+    L.orc_bgr_to_gray.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.orc_bgr_to_gray(_p(bgr), out.size, _p(out))
+    return out
+
+
+def depth_to_cloud(depth: np.ndarray, x_to_z: float, y_to_z: float) -> np.ndarray:
+    """DepthToPointCloud::operator(), /root/reference/helper.cpp:30-53.  depth: [H, W] u16 -> [H, W, 3] f32"""
+    depth = np.ascontiguousarray(depth, np.uint16)
+    h, w = depth.shape
+    out = np.empty((h, w, 3), np.float32)
+    L = lib()
+    L.orc_depth_to_cloud.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
+    L.orc_depth_to_cloud(_p(depth), w, h, x_to_z, y_to_z, _p(out))
+    return out
+
+
 class Oracle:
     def __init__(self, intr: dict, params: Params | None = None):
         self.L = lib()

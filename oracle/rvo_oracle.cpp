@@ -1457,6 +1457,30 @@ void orc_pyr_down(const uint8_t* src, int stride, int w, int h, uint8_t* dst, in
   BuildNextLevel(src, stride, w, h, dst, dst_stride, buf.data());
 }
 
+// ---- front-of-path conversions of the callers: /root/reference/helper.cpp (root directory,
+// namespace rgbdslam), used by hand_held_demo.cpp:248 and pose_graph.cpp:101,128.  Parity unpinned (no fixtures).
+// ConvertBGR2Gray, helper.cpp:55-64: double-weighted sum, left to right, truncated to u8
+void orc_bgr_to_gray(const uint8_t* bgr, size_t npx, uint8_t* gray) {
+  for (size_t i = 0, j = 0; i < npx; ++i, j += 3) gray[i] = 0.114 * bgr[j + 0] + 0.587 * bgr[j + 1] + 0.299 * bgr[j + 2];
+}
+// DepthToPointCloud::operator(), helper.cpp:30-53 (XtoZ = 2*tan(hfov/2), YtoZ = 2*tan(vfov/2), helper.hpp:32-36;
+// width_/height_ are doubles there)
+void orc_depth_to_cloud(const uint16_t* raw_depth, int w, int h, double xtoz, double ytoz, float* cloud) {
+  const double width = w, height = h;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const int idx = y * w + x;
+      float z = raw_depth[idx] * 0.001;
+      if (std::isnan(z)) {
+        cloud[idx * 3 + 0] = 0; cloud[idx * 3 + 1] = 0; cloud[idx * 3 + 2] = 0;
+      } else {
+        cloud[idx * 3 + 0] = (static_cast<double>(x) / width - 0.5) * z * xtoz;
+        cloud[idx * 3 + 1] = (0.5 - static_cast<double>(y) / height) * z * ytoz;
+        cloud[idx * 3 + 2] = z;
+      }
+    }
+}
+
 void orc_initial_rotation(void* cv, int prev_slot, int cur_slot, double* q_wxyz) {
   Ctx* c = (Ctx*)cv;
   Quat q = c->est.EstimateInitialRotation(c->slot(prev_slot), c->slot(cur_slot));

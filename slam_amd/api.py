@@ -138,6 +138,15 @@ class Context:
         ip = None if init_pose is None else np.ascontiguousarray(init_pose, np.float64).reshape(n, 12)
         self._chk(self.L.rvo_match_frames_dev(self.h, n, C.c_void_p(gray_ptr), C.c_void_p(depth_ptr), _ptr(thr), _ptr(slots), _ptr(ip)))
 
+    def bgr_to_gray_dev(self, n, bgr_ptr, gray_ptr):
+        """ConvertBGR2Gray (helper.cpp:55-64) for n frames in device memory; async."""
+        self._chk(self.L.rvo_bgr_to_gray_dev(self.h, n, C.c_void_p(bgr_ptr), C.c_void_p(gray_ptr)))
+
+    def depth_to_point_cloud_dev(self, n, depth_ptr, x_to_z, y_to_z, cloud_ptr):
+        """DepthToPointCloud::operator() (helper.cpp:30-53) for n depth images in device memory; async."""
+        self._chk(self.L.rvo_depth_to_point_cloud_dev(self.h, n, C.c_void_p(depth_ptr), float(x_to_z), float(y_to_z),
+                                                      C.c_void_p(cloud_ptr)))
+
     def pair_results(self, n):
         out = (PairResult * n)()
         self._chk(self.L.rvo_get_pair_results(self.h, n, out))

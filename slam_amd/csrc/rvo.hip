@@ -12,6 +12,7 @@
 
 #include "kernels_frame.h"
 #include "kernels_pair.h"
+#include "kernels_io.h"
 #include "rvo_dev.h"
 
 static thread_local std::string g_err;

@@ -192,3 +192,19 @@ def test_defaults_match_reference_settings():
     assert q.num_pyramid_levels == 4 and q.fast_adaptive_gain == 0.01 and q.min_features_for_estimate == 12
     with pytest.raises(KeyError):
         params_from_options({"no-such-option": "1"})
+
+
+def test_front_of_path_conversions_known_answers():
+    """ConvertBGR2Gray / DepthToPointCloud restatements (helper.cpp:30-64) against values worked out by hand in
+    Python floats (IEEE double, same operation order)."""
+    from oracle import pyoracle
+    px = np.array([[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 77]], np.uint8)
+    want = [int((0.114 * float(b) + 0.587 * float(g)) + 0.299 * float(r)) for b, g, r in px]
+    assert pyoracle.bgr_to_gray(px).tolist() == want
+    assert want[1] == 0 and want[2] == 29 and want[3] == 149 and want[4] == 76
+    d = np.array([[0, 1000], [2000, 65535]], np.uint16)
+    c = pyoracle.depth_to_cloud(d, 1.2, 0.9)
+    z = np.float32(1000 * 0.001)
+    assert c[0, 1, 2] == z and c[0, 1, 0] == np.float32((1 / 2 - 0.5) * float(z) * 1.2)
+    assert c[0, 1, 1] == np.float32((0.5 - 0 / 2) * float(z) * 0.9)
+    assert c[0, 0, 2] == 0 and np.signbit(c[0, 0, 0])  # (0/W - 0.5) * 0 = -0.0, kept
