@@ -148,6 +148,11 @@ int rvo_match_frames_dev(rvo_ctx* ctx, int n, const uint8_t* gray_dev, const uin
 int rvo_bgr_to_gray_dev(rvo_ctx* ctx, int n, const uint8_t* bgr_dev, uint8_t* gray_dev);
 int rvo_depth_to_point_cloud_dev(rvo_ctx* ctx, int n, const uint16_t* depth_dev, double x_to_z, double y_to_z,
                                  float* cloud_dev);
+
+/* PoseGraphOptimizer::AddEdge (pose_graph.cpp:254-270): information matrix of each of the first n pair results,
+ * info = cov.inverse() (6x6, row-major = column-major: symmetric up to rounding), computed on the device in one
+ * launch; zeros for pairs whose status is not RVO_SUCCESS.  Synchronises. */
+int rvo_get_pair_information(rvo_ctx* ctx, int n, double* info36);
 int rvo_get_pair_results(rvo_ctx* ctx, int n, rvo_pair_result* out);
 /* EstimateInitialRotation alone: q[n][4] = (w,x,y,z) */
 int rvo_initial_rotation(rvo_ctx* ctx, int n, const int32_t* prev_slots, const int32_t* cur_slots, double* q_wxyz);

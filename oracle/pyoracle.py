@@ -87,6 +87,14 @@ def bgr_to_gray(bgr: np.ndarray) -> np.ndarray:
     return out
 
 
+def information(cov: np.ndarray) -> np.ndarray:
+    """info = cov.inverse(), pose_graph.cpp:265 (6x6 partial-pivot elimination)."""
+    cov = np.ascontiguousarray(cov, np.float64).reshape(6, 6)
+    out = np.zeros((6, 6))
+    lib().orc_information(_p(cov), _p(out))
+    return out
+
+
 def depth_to_cloud(depth: np.ndarray, x_to_z: float, y_to_z: float) -> np.ndarray:
     """DepthToPointCloud::operator(), /root/reference/helper.cpp:30-53.  depth: [H, W] u16 -> [H, W, 3] f32"""
     depth = np.ascontiguousarray(depth, np.uint16)

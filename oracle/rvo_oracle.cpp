@@ -1481,6 +1481,15 @@ void orc_depth_to_cloud(const uint16_t* raw_depth, int w, int h, double xtoz, do
     }
 }
 
+// PoseGraphOptimizer::AddEdge, pose_graph.cpp:265: info = covariance.inverse() (Eigen fixed 6x6 -> partial-pivot LU)
+int orc_information(const double* cov36, double* info36) {
+  double A[6][6], inv[6][6];
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) A[i][j] = cov36[i * 6 + j];
+  const bool ok = inverse6(A, inv);
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) info36[i * 6 + j] = inv[i][j];
+  return ok ? 1 : 0;
+}
+
 void orc_initial_rotation(void* cv, int prev_slot, int cur_slot, double* q_wxyz) {
   Ctx* c = (Ctx*)cv;
   Quat q = c->est.EstimateInitialRotation(c->slot(prev_slot), c->slot(cur_slot));

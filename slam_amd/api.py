@@ -147,6 +147,12 @@ class Context:
         self._chk(self.L.rvo_depth_to_point_cloud_dev(self.h, n, C.c_void_p(depth_ptr), float(x_to_z), float(y_to_z),
                                                       C.c_void_p(cloud_ptr)))
 
+    def pair_information(self, n):
+        """info = cov.inverse() of the first n pair results (pose_graph.cpp:265), [n, 6, 6]; zeros where not SUCCESS."""
+        out = np.zeros((n, 6, 6))
+        self._chk(self.L.rvo_get_pair_information(self.h, n, _ptr(out)))
+        return out
+
     def pair_results(self, n):
         out = (PairResult * n)()
         self._chk(self.L.rvo_get_pair_results(self.h, n, out))
@@ -259,11 +265,14 @@ def stream_result_to_dict(r: StreamResult) -> dict:
 
 
 class FrameMatcher:
-    """rgbdvo::FrameMatcher (fm.hpp:14-44) at batch size 1: SetRefFrame / Match / GetMotionEstimate / GetCov."""
+    """rgbdvo::FrameMatcher (fm.hpp:14-44) at batch size 1: SetRefFrame / Match / GetMotionEstimate / GetCov, plus the
+    batched loop closure of SURVEY.md section 8f row 1 (CacheKeyFrame / MatchCachedKeyFrames): keyframes stay prepared
+    on the device and PoseGraph::LinearLoopClosure's candidate loop (pose_graph.cpp:85-145) is ONE rvo_match_pairs."""
 
-    def __init__(self, intr: dict, options: dict | None = None, device: int = 0):
-        self.ctx = Context(intr, params_from_options(options or {}, frame_matcher=True), max_frames=2, max_pairs=1,
-                           device=device)
+    def __init__(self, intr: dict, options: dict | None = None, device: int = 0, max_keyframes: int = 0):
+        self.ctx = Context(intr, params_from_options(options or {}, frame_matcher=True), max_frames=2 + max_keyframes,
+                           max_pairs=max(1, max_keyframes), device=device)
+        self.max_keyframes = max_keyframes
         self.thr = self.ctx.params.fast_init_threshold
         self.result = None
 
@@ -282,6 +291,22 @@ class FrameMatcher:
 
     def GetCov(self):
         return self.result["cov"]
+
+    def CacheKeyFrame(self, kf_id: int, gray, raw_depth):
+        assert 0 <= kf_id < self.max_keyframes
+        self.ctx.prepare_frames(gray, raw_depth, self.thr, [2 + kf_id])
+
+    def MatchCachedKeyFrames(self, ref_id: int, target_ids):
+        """[(target_id, valid, motion 4x4, cov 6x6, information 6x6)] for every candidate, in one batch."""
+        t = [2 + int(i) for i in target_ids]
+        res = self.ctx.match_pairs([2 + ref_id] * len(t), t)
+        info = self.ctx.pair_information(len(t))
+        out = []
+        for k, r in enumerate(res):
+            m = np.eye(4)
+            m[:3] = r["pose"]
+            out.append((int(target_ids[k]), r["status"] == 1, m, r["cov"], info[k]))
+        return out
 
 
 class RGBDVOStreams:

@@ -1342,6 +1342,24 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, E
   }
 }
 
+// ------------------------------------------------------------------ edge information for the pose graph
+// PoseGraphOptimizer::AddEdge (pose_graph.cpp:254-270): info = edge.covariance.inverse(), one 6x6 partial-pivot
+// inverse per accepted pair.  One thread per pair; pairs without a valid estimate get zeros.
+__global__ void k_pair_information(PairBufs pb, int n, double* __restrict__ info) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const rvo_pair_result* r = pb.result + i;
+  double* o = info + (size_t)i * 36;
+  if (r->status != RVO_SUCCESS) {
+    for (int k = 0; k < 36; k++) o[k] = 0;
+    return;
+  }
+  double A[36], inv[36];
+  for (int k = 0; k < 36; k++) A[k] = r->cov[k];
+  inverse6(A, inv);
+  for (int k = 0; k < 36; k++) o[k] = inv[k];
+}
+
 // ------------------------------------------------------------------ streaming state machine (vo.cpp:55-165)
 struct StreamState {
   int init_cnt, frame_cnt, ref_changed_flag, fast_thr;

@@ -57,6 +57,7 @@ struct rvo_ctx {
   int n_streams = 0;
   int32_t* d_sslots = nullptr;  // [2n]: current slot (-1 = warm-up skip), FAST threshold (device-written)
   double* d_pinit = nullptr;
+  double* d_info = nullptr;  // [max_pairs][36] edge information matrices
   int lds_rot = 0, lds_match = 0, lds_clique = 0;
   // pinned ring for small host->device argument arrays (slot lists, thresholds, initial poses)
   static const int kRing = 32;

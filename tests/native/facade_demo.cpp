@@ -54,5 +54,18 @@ int main(int argc, char** argv) {
     for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) printf(" %.17g", T.matrix()(r, c));
     printf(" %.17g\n", fm.GetCov()(0, 0));
   }
+  // batched loop closure on cached keyframes (pose_graph.cpp:85-145 as one call) + edge information (pose_graph.cpp:265)
+  rgbdvo::FrameMatcher lc(camera, rgbdvo::GetFrameMatcherDefaultOptions(), 0, N);
+  for (int i = 0; i < N; i++) lc.CacheKeyFrame(i, gray[i].data(), depth[i].data());
+  std::vector<int> cand;
+  for (int i = 0; i + 1 < N; i++) cand.push_back(i);
+  std::vector<rgbdvo::LoopClosureEdge> edges;
+  const int nok = lc.MatchCachedKeyFrames(N - 1, cand, &edges);
+  printf("LC %d %d\n", (int)edges.size(), nok);
+  for (const auto& e : edges) {
+    printf("LCE %d %d %d", e.target_id, (int)e.valid, e.num_inliers);
+    for (int k = 0; k < 12; k++) printf(" %.17g", e.motion[k]);
+    printf(" %.17g %.17g\n", e.cov[0], e.information[0]);
+  }
   return 0;
 }

@@ -52,3 +52,25 @@ def test_cpp_facade_matches_python_mirror(scene, tmp_path):
         assert int(l[2]) == int(ok) and int(l[3]) == 6
         assert np.array_equal(np.array(l[4:16], float).reshape(3, 4), fm.GetMotionEstimate()[:3])
         assert float(l[16]) == fm.GetCov()[0, 0]
+
+    # batched loop closure on cached keyframes: C++ facade == Python mirror == one-at-a-time FrameMatcher::Match
+    lce = [l.split() for l in out.stdout.splitlines() if l.startswith("LCE")]
+    assert len(lce) == N - 1
+    lc = FrameMatcher(intr, max_keyframes=N)
+    for i, (g, d, _) in enumerate(seq):
+        lc.CacheKeyFrame(i, g, d)
+    edges = lc.MatchCachedKeyFrames(N - 1, list(range(N - 1)))
+    one = FrameMatcher(intr)
+    one.SetRefFrame(seq[N - 1][0], seq[N - 1][1])
+    from oracle import pyoracle
+    for l, (tid, valid, motion, cov, info) in zip(lce, edges):
+        assert int(l[1]) == tid and int(l[2]) == int(valid)
+        assert np.array_equal(np.array(l[4:16], float).reshape(3, 4), motion[:3])
+        assert float(l[16]) == cov[0, 0] and float(l[17]) == info[0, 0]
+        ok = one.Match(seq[tid][0], seq[tid][1])
+        assert ok == valid and np.array_equal(one.GetMotionEstimate(), motion) and np.array_equal(one.GetCov(), cov)
+        if valid:  # information = cov^-1 (pose_graph.cpp:265): oracle's partial-pivot inverse, and a true inverse
+            np.testing.assert_allclose(info, pyoracle.information(cov), rtol=1e-9, atol=0)
+            np.testing.assert_allclose(info @ cov, np.eye(6), atol=1e-6)
+        else:
+            assert not info.any()
