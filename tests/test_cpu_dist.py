@@ -48,3 +48,27 @@ def test_shard_range_covers_everything():
         for w in (1, 2, 3, 8):
             idx = [i for r in range(w) for i in shard_range(n, r, w)]
             assert idx == list(range(n))
+
+
+def test_vertex_file_format_roundtrip(tmp_path):
+    """struct Vertex {uint32 id; Matrix4d pose} records (pose_graph.hpp:51-57): 144 bytes, id at 0, column-major pose at 16."""
+    import struct
+    import numpy as np
+    from slam_amd import vertex_io
+    rng = np.random.default_rng(3)
+    poses = rng.normal(size=(5, 3, 4))
+    ids = [0, 1, 2, 7, 9]
+    p = str(tmp_path / "v.bin")
+    vertex_io.save_vertices(p, ids[:3], poses[:3])
+    vertex_io.save_vertices(p, ids[3:], poses[3:], append=True)  # SaveVertexById appends
+    raw = open(p, "rb").read()
+    assert len(raw) == 5 * 144
+    # decode record 3 by hand, the way the C++ struct lies in memory
+    rid, = struct.unpack_from("<I", raw, 3 * 144)
+    col_major = struct.unpack_from("<16d", raw, 3 * 144 + 16)
+    assert rid == 7
+    assert col_major[4 * 3 + 1] == poses[3, 1, 3]      # element (row 1, col 3) at index col*4 + row
+    assert col_major[3::4] == (0.0, 0.0, 0.0, 1.0)     # last row of the homogeneous matrix
+    got_ids, got = vertex_io.load_vertices(p)
+    assert got_ids.tolist() == ids and np.array_equal(got[:, :3], poses)
+    assert np.array_equal(vertex_io.load_vertex_by_id(p, 9)[:3], poses[4]) and vertex_io.load_vertex_by_id(p, 5) is None
