@@ -136,7 +136,10 @@ int rvo_match_pairs_async(rvo_ctx* ctx, int n, const int32_t* ref_slots, const i
  * (rgbdvo/frame.cpp:38-149) into slots[2i], slots[2i+1] with FAST thresholds fast_thr[2i], fast_thr[2i+1], then pair
  * work area i estimates slots[2i] -> slots[2i+1] exactly as rvo_match_pairs_async does.  The batch is cut into
  * chunks that run the whole frame+pair pipeline on separate HIP streams, so the latency-bound pair stages of one
- * chunk overlap the throughput-bound frame stages of another.  Enqueues only; results via rvo_get_pair_results. */
+ * chunk overlap the throughput-bound frame stages of another.  Enqueues only; results via rvo_get_pair_results.
+ * The gray images are copied into the slots; the depth images are NOT: they are sampled in place (a few KB per
+ * frame), so depth_dev must stay valid and unchanged for as long as these slots are used (until they are prepared
+ * again), e.g. by a later rvo_match_pairs that names them. */
 int rvo_match_frames_dev(rvo_ctx* ctx, int n, const uint8_t* gray_dev, const uint16_t* depth_dev, const int32_t* fast_thr,
                          const int32_t* slots, const double* init_pose);
 

@@ -67,9 +67,11 @@ __device__ inline int block_excl_scan(int v, int* s_wave, int* total) {
 // ------------------------------------------------------------------ ingest
 // Level-0 copy (frame.cpp:47-50) and raw depth copy into the frame slots; grid (blocks, n_frames).
 // VEC: 16-byte path (W % 16 == 0, Wd*Hd % 8 == 0 and 16-byte aligned sources).
+// copy_depth = 0: the depth image is not copied; the slot's depth_tab entry points at the caller's buffer instead
+// (depth is only sampled at keypoints and refined matches, ~5 KB of the 614 KB image).
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_ingest(FrameBufs fb, FrameGeom g, const uint8_t* __restrict__ gray,
-                                                const uint16_t* __restrict__ depth, const int32_t* __restrict__ slots) {
+                                                const uint16_t* __restrict__ depth, const int32_t* __restrict__ slots, int copy_depth) {
   const int f = blockIdx.y;
   const int slot = slots[f];
   if (slot < 0) return;
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(256) void k_ingest(FrameBufs fb, FrameGeom g, const
   uint8_t* gd = fb.img + (size_t)slot * g.img_bytes + g.lv[0].img_off;
   uint16_t* dd = fb.depth + (size_t)slot * ndp;
   const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+  if (tid == 0) fb.depth_tab[slot] = copy_depth ? dd : dsrc;
   if (VEC) {
     const int cpr = g.W / 16, spr = g.lv[0].stride / 16;
     const uint4* s4 = reinterpret_cast<const uint4*>(gs);
@@ -86,10 +89,12 @@ __global__ __launch_bounds__(256) void k_ingest(FrameBufs fb, FrameGeom g, const
     for (int i = tid; i < cpr * g.H; i += nth) d4[(i / cpr) * spr + i % cpr] = s4[i];
     const uint4* ds4 = reinterpret_cast<const uint4*>(dsrc);
     uint4* dd4 = reinterpret_cast<uint4*>(dd);
-    for (int i = tid; i < (int)(ndp / 8); i += nth) dd4[i] = ds4[i];
+    if (copy_depth)
+      for (int i = tid; i < (int)(ndp / 8); i += nth) dd4[i] = ds4[i];
   } else {
     for (int i = tid; i < (int)npx; i += nth) gd[(size_t)(i / g.W) * g.lv[0].stride + i % g.W] = gs[i];
-    for (int i = tid; i < (int)ndp; i += nth) dd[i] = dsrc[i];
+    if (copy_depth)
+      for (int i = tid; i < (int)ndp; i += nth) dd[i] = dsrc[i];
   }
 }
 
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
   if (slot < 0) return;
   const LevelGeom G = g.lv[lvl];
   const uint8_t* __restrict__ img = fb.img + (size_t)slot * g.img_bytes + G.img_off;
-  const uint16_t* __restrict__ depth = fb.depth + (size_t)slot * g.Wd * g.Hd;
+  const uint16_t* __restrict__ depth = fb.depth_tab[slot];
   const int32_t* bk_cnt = fb.bk_cnt + (size_t)slot * g.total_buckets + G.bucket_off;
   const int32_t* bk_det = fb.bk_det + (size_t)slot * g.total_buckets + G.bucket_off;
   const uint32_t* bk_kp = fb.bk_kp + ((size_t)slot * g.total_buckets + G.bucket_off) * g.max_per;

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     }
     status = RVO_MATCH_REFINEMENT_FAILED;
     {  // Depth::GetXYZInterp on the target frame's depth, depth.cpp:97-162
-      const uint16_t* __restrict__ depth = fb.depth + (size_t)ts * g.Wd * g.Hd;
+      const uint16_t* __restrict__ depth = fb.depth_tab[ts];
       const float u_f = (float)rect0, v_f = (float)rect1;
       const float v_f_d = v_f * g.ys, u_f_d = u_f * g.xs;
       const int v = (int)v_f_d, u = (int)u_f_d;

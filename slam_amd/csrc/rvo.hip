@@ -271,6 +271,7 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   const size_t F = max_frames;
   rc |= dalloc(c, &fb.img, F * g.img_bytes);
   rc |= dalloc(c, &fb.depth, F * g.Wd * g.Hd);
+  rc |= dalloc(c, &fb.depth_tab, F);
   rc |= dalloc(c, &fb.bk_cnt, F * g.total_buckets);
   rc |= dalloc(c, &fb.bk_det, F * g.total_buckets);
   rc |= dalloc(c, &fb.bk_kp, F * g.total_buckets * g.max_per);
@@ -287,6 +288,11 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   rc |= dalloc(c, &c->d_fargs, 2 * F);
   if (rc) { rvo_destroy(c); return RVO_E_NOMEM; }
   HIPCHK(hipMemset(fb.img, 0, F * g.img_bytes));  // PyramidLevel ctor memset, pyramid.cpp:121
+  {
+    std::vector<const uint16_t*> tab(F);
+    for (size_t i = 0; i < F; i++) tab[i] = fb.depth + i * (size_t)g.Wd * g.Hd;
+    HIPCHK(hipMemcpy(fb.depth_tab, tab.data(), F * sizeof(tab[0]), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMemset(fb.kp_cnt, 0, F * RVO_MAX_LEVELS * 4));
   HIPCHK(hipMemset(fb.det_cnt, 0, F * RVO_MAX_LEVELS * 4));
   HIPCHK(hipMemset(fb.grid_cnt, 0, F * RVO_MAX_LEVELS * 4));
@@ -353,15 +359,16 @@ static int ensure_stage(rvo_ctx* c, int n) {
   return RVO_OK;
 }
 
-static int launch_ingest_on(rvo_ctx* c, hipStream_t st, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots) {
+static int launch_ingest_on(rvo_ctx* c, hipStream_t st, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots,
+                            int copy_depth) {
   const FrameGeom& g = c->g;
   const bool vec = (g.W % 16 == 0) && (((size_t)g.Wd * g.Hd) % 8 == 0) && (((uintptr_t)gray & 15) == 0) && (((uintptr_t)depth & 15) == 0);
-  if (vec) LAUNCH_ON(c, st, "ingest", k_ingest<true>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots);
-  else LAUNCH_ON(c, st, "ingest", k_ingest<false>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots);
+  if (vec) LAUNCH_ON(c, st, "ingest", k_ingest<true>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots, copy_depth);
+  else LAUNCH_ON(c, st, "ingest", k_ingest<false>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots, copy_depth);
   return RVO_OK;
 }
 static int launch_ingest(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots) {
-  return launch_ingest_on(c, c->stream, n, gray, depth, d_slots);
+  return launch_ingest_on(c, c->stream, n, gray, depth, d_slots, 1);
 }
 
 // ---------------------------------------------------------------- PrepareFrame

@@ -41,6 +41,8 @@ __host__ __device__ inline int kp_s(uint32_t k) { return k >> 22; }
 struct FrameBufs {
   uint8_t* img;       // [slots][img_bytes]
   uint16_t* depth;    // [slots][Wd*Hd] raw millimetres, 0 = invalid (vo.cpp:83-87 conversion is done lazily)
+  const uint16_t** depth_tab;  // [slots] where the slot's depth image lives: its block of `depth`, or (rvo_match_frames_dev)
+                               // the caller's device buffer, read in place
   int32_t* bk_cnt;    // [slots][total_buckets] kept per bucket (<= max_per)
   int32_t* bk_det;    // [slots][total_buckets] NMS survivors per bucket
   uint32_t* bk_kp;    // [slots][total_buckets][max_per] packed, post-nth_element order
