@@ -1103,17 +1103,18 @@ __device__ inline void inverse6(const double* A, double* inv) {
 }
 
 struct GnShared {
-  JacMats fwd, rev;
-  double Pf[12], Pr[12];   // K(fx,fx)*motion and K(fx,fx)*motion^-1 for the error at the current estimate
-  double Pnf[12], Pnr[12]; // same at the trial estimate
+  JacMats jac[2];          // forward, reverse
+  double P[2][12];         // K(fx,fx)*motion and K(fx,fx)*motion^-1 for the error at the current estimate
+  double PN[2][12];        // same at the trial estimate
   double est[6], next[6], delta[6];
   double motion[12], nmotion[12];
   double final_sse;
   int stop, status, n_inl;
 };
 
-#define GN_THREADS 256
-// grid (n_pairs), GN_THREADS threads: one workgroup per pair (512 or 1024 threads were measured 3-6x slower: the fp64 Jacobians spill).
+#define GN_THREADS 512
+// grid (n_pairs), GN_THREADS threads: one workgroup per pair, two waves per SIMD (207 VGPRs; with the Jacobians
+// hoisted into registers the kernel needed 502 and could only run one).
 __global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, EstParams ep) {
   __shared__ GnShared S;
   __shared__ double s_big[27 * 256 + 27 * 8];
@@ -1164,28 +1165,30 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, E
       DIso m;
       iso_load(m, S.motion);
       iso_to_params(m, S.est);
-      set_P(m, S.Pf, S.Pr);
+      set_P(m, S.P[0], S.P[1]);
       S.stop = 0;
     }
     __syncthreads();
     {
-      double v[1] = {err_sse(S.Pf, S.Pr)};
+      double v[1] = {err_sse(S.P[0], S.P[1])};
       block_sum_lds<1, GN_THREADS>(v, s_big);
       if (tid == 0) S.final_sse = v[0];
     }
     for (int it = 0; it < 6; it++) {
-      if (tid == 0) forward_jac_mats(S.est, fx, px, py, S.fwd);
-      if (tid == 64) reverse_jac_mats(S.est, fx, px, py, S.rev);
+      if (tid == 0) forward_jac_mats(S.est, fx, px, py, S.jac[0]);
+      if (tid == 64) reverse_jac_mats(S.est, fx, px, py, S.jac[1]);
       __syncthreads();
       double acc[27];
 #pragma unroll
       for (int k = 0; k < 27; k++) acc[k] = 0;
-      for (int i = tid; i < N; i += GN_THREADS) {
+      // one (match, direction) item per thread and trip: the Jacobian matrices are read from LDS by direction, which
+      // keeps them out of the register file (two waves per SIMD instead of one)
+      for (int item = tid; item < 2 * N; item += GN_THREADS) {
+        const int i = item >> 1, dir = item & 1;
         if (!pb.m_inlier[mb + i]) continue;
-#pragma unroll
-        for (int dir = 0; dir < 2; dir++) {
-          const JacMats& J = dir ? S.rev : S.fwd;
-          const double* Pe = dir ? S.Pr : S.Pf;
+        {
+          const JacMats& J = S.jac[dir];
+          const double* Pe = S.P[dir];
           const double* pt = (dir ? pb.m_rxyz : pb.m_xyz) + (mb + i) * 3;
           const double* pj = (dir ? pb.m_rect : pb.m_rrect) + (mb + i) * 2;
           const double x = pt[0], y = pt[1], z = pt[2];
@@ -1223,12 +1226,12 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, E
           next[a] = S.est[a] + s;
         }
         const DIso nest = iso_from_params(next);
-        set_P(nest, S.Pnf, S.Pnr);
+        set_P(nest, S.PN[0], S.PN[1]);
         for (int a = 0; a < 6; a++) { S.next[a] = next[a]; S.delta[a] = delta[a]; }
         iso_store(nest, S.nmotion);
       }
       __syncthreads();
-      double v[1] = {err_sse(S.Pnf, S.Pnr)};
+      double v[1] = {err_sse(S.PN[0], S.PN[1])};
       block_sum_lds<1, GN_THREADS>(v, s_big);
       if (tid == 0) {
         const double sse = v[0];
@@ -1237,7 +1240,7 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, E
         } else {
           for (int a = 0; a < 6; a++) S.est[a] = S.next[a];
           S.final_sse = sse;
-          for (int k = 0; k < 12; k++) { S.motion[k] = S.nmotion[k]; S.Pf[k] = S.Pnf[k]; S.Pr[k] = S.Pnr[k]; }
+          for (int k = 0; k < 12; k++) { S.motion[k] = S.nmotion[k]; S.P[0][k] = S.PN[0][k]; S.P[1][k] = S.PN[1][k]; }
           const double rt = 0.01 * M_PI / 180;
           const double* d = S.delta;
           if (fabs(d[0]) < 0.0001 && fabs(d[1]) < 0.0001 && fabs(d[2]) < 0.0001 && fabs(d[3]) < rt && fabs(d[4]) < rt && fabs(d[5]) < rt) S.stop = 1;
@@ -1248,17 +1251,17 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, E
     }
     // covariance = (M'M)^-1 at the final parameters, motion_estimate.cpp:1319-1329
     __syncthreads();
-    if (tid == 0) forward_jac_mats(S.est, fx, px, py, S.fwd);
-    if (tid == 64) reverse_jac_mats(S.est, fx, px, py, S.rev);
+    if (tid == 0) forward_jac_mats(S.est, fx, px, py, S.jac[0]);
+    if (tid == 64) reverse_jac_mats(S.est, fx, px, py, S.jac[1]);
     __syncthreads();
     double acc[21];
 #pragma unroll
     for (int k = 0; k < 21; k++) acc[k] = 0;
-    for (int i = tid; i < N; i += GN_THREADS) {
+    for (int item = tid; item < 2 * N; item += GN_THREADS) {
+      const int i = item >> 1, dir = item & 1;
       if (!pb.m_inlier[mb + i]) continue;
-#pragma unroll
-      for (int dir = 0; dir < 2; dir++) {
-        const JacMats& J = dir ? S.rev : S.fwd;
+      {
+        const JacMats& J = S.jac[dir];
         const double* pt = (dir ? pb.m_rxyz : pb.m_xyz) + (mb + i) * 3;
         const double x = pt[0], y = pt[1], z = pt[2];
         const double u = dot4(J.P, x, y, z, 1.0), v = dot4(J.P + 4, x, y, z, 1.0), w = dot4(J.P + 8, x, y, z, 1.0);
@@ -1297,14 +1300,14 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, E
     if (tid == 0) {
       DIso m;
       iso_load(m, S.motion);
-      proj_matrix(cam.fx, cam.fy, cam.cx, cam.cy, m, S.Pnf);
+      proj_matrix(cam.fx, cam.fy, cam.cx, cam.cy, m, S.PN[0]);
     }
     __syncthreads();
     double v[1] = {0};
     for (int i = tid; i < N; i += GN_THREADS) {
       if (!pb.m_inlier[mb + i]) continue;
       const double* t = pb.m_xyz + (mb + i) * 3;
-      const double h0 = dot4(S.Pnf, t[0], t[1], t[2], 1.0), h1 = dot4(S.Pnf + 4, t[0], t[1], t[2], 1.0), h2 = dot4(S.Pnf + 8, t[0], t[1], t[2], 1.0);
+      const double h0 = dot4(S.PN[0], t[0], t[1], t[2], 1.0), h1 = dot4(S.PN[0] + 4, t[0], t[1], t[2], 1.0), h2 = dot4(S.PN[0] + 8, t[0], t[1], t[2], 1.0);
       const double ex = pb.m_rrect[(mb + i) * 2] - h0 / h2, ey = pb.m_rrect[(mb + i) * 2 + 1] - h1 / h2;
       const double e = sqrt(ex * ex + ey * ey);
       pb.m_reproj[mb + i] = e;
