@@ -505,7 +505,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom
 // ------------------------------------------------------------------ sub-pixel refinement
 __device__ inline int desc_off(int i, int stride) { return (i / 9 - 4) * stride + (i % 9 - 4); }
 
-struct Wts { float wa, wb, wc, wd; int base; };
+struct Wts { float wa, wb, wc, wd; int base, u, v; };
 // bilinear weights of Descriptor::ExtractInterpDescriptor, feature.cpp:6116-6124
 __device__ inline Wts make_wts(float x, float y, int stride) {
   const int u = (int)x, v = (int)y;
@@ -516,6 +516,7 @@ __device__ inline Wts make_wts(float x, float y, int stride) {
   w.wc = (float)((1. - (double)wr) * (double)wbm);
   w.wd = wr * wbm;
   w.base = v * stride + u;
+  w.u = u; w.v = v;
   return w;
 }
 __device__ inline int interp_raw(const uint8_t* __restrict__ gimg, int stride, const Wts& w, int i) {
@@ -541,6 +542,8 @@ __device__ inline int group16_sum(int v) {
 
 #define REFINE_GROUP 16
 #define REFINE_TAPS (RVO_DESC_LEN / REFINE_GROUP)  // 5 taps per lane
+#define REFINE_WIN_ROWS 16
+#define REFINE_WIN_PITCH 20
 // grid (ceil(kp_total/16), n_pairs), 256 threads: 16 lanes per match, 5 descriptor taps per lane; all sums are exact
 // int32, so the lane split does not change any value.  Branches below are uniform within a 16-lane group.
 __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
@@ -557,6 +560,9 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
   // per match of this workgroup: the refined position handed to the finishing lanes
   __shared__ float s_tx[256 / REFINE_GROUP], s_ty[256 / REFINE_GROUP];
   __shared__ int s_r[256 / REFINE_GROUP], s_t[256 / REFINE_GROUP];
+  // 16x16 target window around the matched keypoint (rows of 5 aligned dwords): positions within +-3 px of it, i.e.
+  // practically every ESM step, read their 10x10 taps from LDS instead of paying an L2 round trip per iteration
+  __shared__ __align__(4) uint8_t s_win[256 / REFINE_GROUP][REFINE_WIN_ROWS * REFINE_WIN_PITCH];
   if (i_grp < N) {
   const int i = i_grp;
   int lvl = 0;
@@ -578,10 +584,39 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
   // the four bilinear neighbours of a tap; the first three are also the taps of the target gradient at the same
   // integer position (motion_estimate.cpp:800-815), so an accepted step needs no further loads for the next one
   struct Nb { int p00, p01, p10; };
-  auto interp = [&](const Wts& w, int o, Nb& nb) -> int {
-    const int k = w.base + o;
-    nb.p00 = tg[k]; nb.p01 = tg[k + 1]; nb.p10 = tg[k + S];
-    const float f = ((w.wa * (float)nb.p00 + w.wb * (float)nb.p01) + w.wc * (float)nb.p10) + w.wd * (float)tg[k + S + 1];
+  uint8_t* win = s_win[threadIdx.x / REFINE_GROUP];
+  const int ox = kp_x(tkp) - 7, oy = kp_y(tkp) - 7;  // window = columns ox..ox+15, rows oy..oy+15
+  const int xa = ox & ~3;                             // aligned column the stored rows start at
+  {
+    const int y = oy + gl;  // lane gl stages row gl
+    uint32_t dw[REFINE_WIN_PITCH / 4];
+#pragma unroll
+    for (int q = 0; q < REFINE_WIN_PITCH / 4; q++) {
+      const int x = xa + 4 * q;
+      dw[q] = (y >= 0 && y < G.h && x >= 0 && x + 3 < S) ? *reinterpret_cast<const uint32_t*>(tg + y * S + x) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < REFINE_WIN_PITCH / 4; q++) reinterpret_cast<uint32_t*>(win + gl * REFINE_WIN_PITCH)[q] = dw[q];
+  }
+  wavealgo::wave_lds_sync();  // the 16 lanes of a group are in one wave
+  int woff[REFINE_TAPS];
+#pragma unroll
+  for (int m = 0; m < REFINE_TAPS; m++) {
+    const int t9 = gl + REFINE_GROUP * m;
+    woff[m] = (t9 / 9 - 4) * REFINE_WIN_PITCH + (t9 % 9 - 4);
+  }
+  // interpolated tap m at integer position (u, v) with weights w; uniform branch per 16-lane group
+  auto interp = [&](const Wts& w, int m, Nb& nb) -> int {
+    const int u = w.u, v = w.v;
+    int p11;
+    if (u - 4 >= ox && u + 5 <= ox + 15 && v - 4 >= oy && v + 5 <= oy + 15) {
+      const uint8_t* q = win + (v - oy) * REFINE_WIN_PITCH + (u - xa) + woff[m];
+      nb.p00 = q[0]; nb.p01 = q[1]; nb.p10 = q[REFINE_WIN_PITCH]; p11 = q[REFINE_WIN_PITCH + 1];
+    } else {
+      const int k = w.base + toff[m];
+      nb.p00 = tg[k]; nb.p01 = tg[k + 1]; nb.p10 = tg[k + S]; p11 = tg[k + S + 1];
+    }
+    const float f = ((w.wa * (float)nb.p00 + w.wb * (float)nb.p01) + w.wc * (float)nb.p10) + w.wd * (float)p11;
     return (int)f;
   };
   const int rbase = kp_y(rkp) * S + kp_x(rkp);
@@ -597,7 +632,7 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     rraw[m] = rg[kr];
     rdx[m] = rg[kr + 1] - rraw[m];
     rdy[m] = rg[kr + S] - rraw[m];
-    traw[m] = interp(wt, toff[m], tnb[m]);
+    traw[m] = interp(wt, m, tnb[m]);
     rsum += rraw[m];
     tsum += traw[m];
   }
@@ -637,7 +672,7 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     Nb nnb[REFINE_TAPS];
     int nsum = 0;
 #pragma unroll
-    for (int m = 0; m < REFINE_TAPS; m++) { nraw[m] = interp(wn, toff[m], nnb[m]); nsum += nraw[m]; }
+    for (int m = 0; m < REFINE_TAPS; m++) { nraw[m] = interp(wn, m, nnb[m]); nsum += nraw[m]; }
     const int nmean = group16_sum(nsum) / RVO_DESC_LEN;
     int sse = 0;
 #pragma unroll
