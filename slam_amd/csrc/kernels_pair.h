@@ -821,6 +821,7 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
     }
     __syncthreads();
     if (!wave_live) continue;
+    uint32_t quad[4] = {0u, 0u, 0u, 0u};
     for (int w0 = 0; w0 < nt; w0 += 32) {
       uint32_t word = 0, amb = 0;
       // branch-free fp32 pass over 32 columns (columns past the tile end read stale-but-finite LDS and are masked)
@@ -858,7 +859,12 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
       const int self = i - (j0 + w0);
       if (self >= 0 && self < 32) word &= ~(1u << self);
       if (!live) word = 0;
-      if (live) row[(j0 + w0) >> 5] = word;
+      // rows are 16-byte aligned and tiles start on multiples of 128 columns: four words per store
+      quad[(w0 >> 5) & 3] = word;
+      if (((w0 >> 5) & 3) == 3 || w0 + 32 >= nt) {
+        if (live) *reinterpret_cast<uint4*>(row + (((j0 + w0) >> 5) & ~3)) = make_uint4(quad[0], quad[1], quad[2], quad[3]);
+        quad[0] = quad[1] = quad[2] = quad[3] = 0u;
+      }
       if (j0 + w0 >= jstart + 256) {
         // transpose: lane b collects the 64-bit column (rows iw0..iw0+63) of column j0+w0+b
         unsigned long long col = 0;
@@ -869,9 +875,8 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
         }
         const int jc = j0 + w0 + lane;
         if (lane < 32 && jc < N) {
-          uint32_t* crow = pb.cbits + (mb + jc) * pb.cwords + (iw0 >> 5);
-          crow[0] = (uint32_t)col;
-          if ((iw0 >> 5) + 1 < pb.cwords) crow[1] = (uint32_t)(col >> 32);
+          // iw0 is a multiple of 64 and cwords a multiple of 4: both words exist and the pair is 8-byte aligned
+          *reinterpret_cast<uint2*>(pb.cbits + (mb + jc) * pb.cwords + (iw0 >> 5)) = make_uint2((uint32_t)col, (uint32_t)(col >> 32));
         }
       }
     }
