@@ -439,7 +439,6 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
   const int slot = slots[blockIdx.y];
   if (slot < 0) return;
   const LevelGeom G = g.lv[lvl];
-  const uint8_t* __restrict__ img = fb.img + (size_t)slot * g.img_bytes + G.img_off;
   const uint16_t* __restrict__ depth = fb.depth_tab[slot];
   const int32_t* bk_cnt = fb.bk_cnt + (size_t)slot * g.total_buckets + G.bucket_off;
   const int32_t* bk_det = fb.bk_det + (size_t)slot * g.total_buckets + G.bucket_off;

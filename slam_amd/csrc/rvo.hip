@@ -404,7 +404,6 @@ int rvo_prepare_frames_dev(rvo_ctx* c, int n, const uint8_t* gray, const uint16_
   for (int i = 0; i < n; i++)
     if (slots[i] < 0 || slots[i] >= c->max_frames) { g_err = "rvo_prepare_frames: slot out of range"; return RVO_E_INVALID; }
   HIPCHK(hipSetDevice(c->device));
-  const FrameGeom& g = c->g;
   std::vector<int32_t> args(2 * (size_t)n);
   memcpy(args.data(), slots, n * 4);
   memcpy(args.data() + n, thr, n * 4);
