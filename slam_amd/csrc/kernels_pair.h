@@ -356,8 +356,8 @@ __device__ inline uint32_t sad80(const uint8_t* a, const uint8_t* b) {
 // SAD and folds it into the per-ref and per-target bests with LDS atomicMin on (score<<16 | index) keys -- the
 // lexicographic minimum is exactly the reference's "strictly smaller score wins, first in iteration order on ties"
 // (feature.cpp:6301-6308).
-#define MATCH_MAX_RUNS 64
-__host__ __device__ inline int match_lds_bytes(int cap) { return cap * 16 + MATCH_MAX_RUNS * 16 + MATCH_WAVES * MATCH_QCAP * 4 + 128; }
+__host__ __device__ inline int match_max_runs(int cap) { return (cap + 63) / 64 + 1; }
+__host__ __device__ inline int match_lds_bytes(int cap) { return cap * 16 + match_max_runs(cap) * 16 + MATCH_WAVES * MATCH_QCAP * 4 + 128; }
 __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, EstParams ep) {
   extern __shared__ __align__(16) uint8_t lds[];
   const int lvl = blockIdx.x, pair = blockIdx.y + pb.pair0, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -368,8 +368,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom
   uint32_t* s_bt = reinterpret_cast<uint32_t*>(lds + (size_t)cap * 8);
   uint32_t* s_br = s_bt + cap;
   float4* s_box = reinterpret_cast<float4*>(s_br + cap);                  // per run: min u, min v, max u, max v
-  uint32_t* s_q = reinterpret_cast<uint32_t*>(s_box + MATCH_MAX_RUNS) + (size_t)wid * MATCH_QCAP;
-  int* s_wave = reinterpret_cast<int*>(reinterpret_cast<uint32_t*>(s_box + MATCH_MAX_RUNS) + (size_t)MATCH_WAVES * MATCH_QCAP);
+  uint32_t* s_q = reinterpret_cast<uint32_t*>(s_box + match_max_runs(cap)) + (size_t)wid * MATCH_QCAP;
+  int* s_wave = reinterpret_cast<int*>(reinterpret_cast<uint32_t*>(s_box + match_max_runs(cap)) + (size_t)MATCH_WAVES * MATCH_QCAP);
   const int rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
   const int nr = fb.kp_cnt[rs * RVO_MAX_LEVELS + lvl], nt = fb.kp_cnt[ts * RVO_MAX_LEVELS + lvl];
   const size_t rbase = (size_t)rs * g.kp_total + G.kp_off, tbase = (size_t)ts * g.kp_total + G.kp_off;
@@ -382,12 +382,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom
   proj_matrix(cam.fx, cam.fy, cam.cx, cam.cy, r2t, RP);
 
   const int nruns = (nt + 63) >> 6;
-  const bool boxed = nruns <= MATCH_MAX_RUNS;
   for (int i0 = wid * 64; i0 < nt; i0 += MATCH_THREADS) {  // whole runs per wave
     const int i = i0 + lane;
     float2 uv = make_float2(0.f, 0.f);
     if (i < nt) { uv = fb.kp_rect[tbase + i]; s_tuv[i] = uv; s_bt[i] = NONE_KEY; }
-    if (boxed) {
+    {
       float mnx = i < nt ? uv.x : INFINITY, mny = i < nt ? uv.y : INFINITY;
       float mxx = i < nt ? uv.x : -INFINITY, mxy = i < nt ? uv.y : -INFINITY;
 #pragma unroll
@@ -423,60 +422,58 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), j);
     return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
   };
-  // wave `wid` owns the reference keypoints wid, wid+16, ...; 64 of them are projected at a time, one per lane
+  // wave `wid` owns the reference keypoints wid, wid+16, ...; 64 of them are projected at a time, one per lane.  Lanes
+  // = references while the run boxes are tested (one broadcast LDS read per run), then every (reference, run) hit is
+  // visited with lanes = the 64 targets of the run.
   for (int rb = wid; rb < nr; rb += MATCH_WAVES * 64) {
     double lpu = 0, lpv = 0;
-    {
-      const int rl = rb + MATCH_WAVES * lane;
-      if (rl < nr) {
-        const double* X = fb.kp_xyz + (rbase + rl) * 3;
-        const double u = dot4(RP, X[0], X[1], X[2], 1.0), v = dot4(RP + 4, X[0], X[1], X[2], 1.0), w = dot4(RP + 8, X[0], X[1], X[2], 1.0);
-        const double inv = 1.0 / w;  // Eigen 3.2 `v /= s` multiplies by the reciprocal
-        lpu = u * inv; lpv = v * inv;
-      }
+    const int rl = rb + MATCH_WAVES * lane;
+    if (rl < nr) {
+      const double* X = fb.kp_xyz + (rbase + rl) * 3;
+      const double u = dot4(RP, X[0], X[1], X[2], 1.0), v = dot4(RP + 4, X[0], X[1], X[2], 1.0), w = dot4(RP + 8, X[0], X[1], X[2], 1.0);
+      const double inv = 1.0 / w;  // Eigen 3.2 `v /= s` multiplies by the reciprocal
+      lpu = u * inv; lpv = v * inv;
     }
-   for (int j = 0; j < 64; j++) {
-    const int r = __builtin_amdgcn_readfirstlane(rb + MATCH_WAVES * j);
-    if (r >= nr) break;
-    const double pu = bcast(lpu, j), pv = bcast(lpv, j);
-    const float fpu = (float)pu, fpv = (float)pv;
-    unsigned long long runs = nruns >= 64 ? ~0ull : ((1ull << nruns) - 1ull);
-    if (boxed) {
-      bool hit = false;
-      if (lane < nruns) {
-        const float4 bx = s_box[lane];
+    const float lfpu = (float)lpu, lfpv = (float)lpv;
+    for (int run = 0; run < nruns; run++) {
+      bool hit = rl < nr;
+      if (hit) {
+        const float4 bx = s_box[run];
         // distance from the projection to the box, in fp64 on exact inputs; fmax drops a NaN projection to 0 (= visit)
-        const double dx = fmax(fmax((double)bx.x - pu, pu - (double)bx.z), 0.0);
-        const double dy = fmax(fmax((double)bx.y - pv, pv - (double)bx.w), 0.0);
+        const double dx = fmax(fmax((double)bx.x - lpu, lpu - (double)bx.z), 0.0);
+        const double dy = fmax(fmax((double)bx.y - lpv, lpv - (double)bx.w), 0.0);
         hit = !(dx * dx + dy * dy > hi2 * (1.0 + 1e-9));
       }
-      runs = __ballot(hit);
-    }
-    while (runs) {
-      const int run = __ffsll((long long)runs) - 1;
-      runs &= runs - 1ull;
+      unsigned long long hm = __ballot(hit);
       const int t = (run << 6) + lane;
-      bool cand = false;
-      if (t < nt) {
-        const float2 uv = s_tuv[t];
-        const float fx = uv.x - fpu, fy = uv.y - fpv;
-        const float fd2 = fx * fx + fy * fy;
-        if (fd2 < flo) {
-          cand = true;
-        } else if (!(fd2 > fhi)) {  // rounding band or NaN: the reference's fp64 evaluation
-          const double ex = (double)uv.x - pu, ey = (double)uv.y - pv;
-          const double d2 = ex * ex + ey * ey;
-          cand = d2 < lo2 ? true : (d2 > hi2 ? false : sqrt(d2) < win);
+      const float2 uv = t < nt ? s_tuv[t] : make_float2(0.f, 0.f);
+      while (hm) {
+        const int j = __ffsll((long long)hm) - 1;
+        hm &= hm - 1ull;
+        const int r = rb + MATCH_WAVES * j;
+        const float fpu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lfpu), j));
+        const float fpv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lfpv), j));
+        bool cand = false;
+        if (t < nt) {
+          const float fx = uv.x - fpu, fy = uv.y - fpv;
+          const float fd2 = fx * fx + fy * fy;
+          if (fd2 < flo) {
+            cand = true;
+          } else if (!(fd2 > fhi)) {  // rounding band or NaN: the reference's fp64 evaluation
+            const double pu = bcast(lpu, j), pv = bcast(lpv, j);
+            const double ex = (double)uv.x - pu, ey = (double)uv.y - pv;
+            const double d2 = ex * ex + ey * ey;
+            cand = d2 < lo2 ? true : (d2 > hi2 ? false : sqrt(d2) < win);
+          }
+        }
+        const unsigned long long m = __ballot(cand);
+        if (m) {
+          if (cand) s_q[qn + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)r << 16) | (uint32_t)t;
+          qn += __popcll(m);
+          if (qn > MATCH_QCAP - 64) flush();
         }
       }
-      const unsigned long long m = __ballot(cand);
-      if (m) {
-        if (cand) s_q[qn + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)r << 16) | (uint32_t)t;
-        qn += __popcll(m);
-        if (qn > MATCH_QCAP - 64) flush();
-      }
     }
-   }
   }
   flush();
   __syncthreads();
