@@ -907,9 +907,13 @@ __global__ __launch_bounds__(CLIQUE_WAVES * 64) void k_clique(PairBufs pb) {
   }
   const int nw = (N + 31) >> 5;
   for (int i = tid; i < N; i += CLIQUE_WAVES * 64) {  // degree = row popcount (motion_estimate.cpp:509-512)
-    const uint32_t* r = pb.cbits + (mb + i) * pb.cwords;
-    int deg = 0;
-    for (int w = 0; w < nw; w++) deg += __popc(r[w]);
+    const uint4* r = reinterpret_cast<const uint4*>(pb.cbits + (mb + i) * pb.cwords);  // rows are 16-byte aligned and
+    int deg = 0;                                                                         // zero beyond column N
+#pragma unroll 4
+    for (int w = 0; w < (nw + 3) >> 2; w++) {
+      const uint4 q = r[w];
+      deg += __popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w);
+    }
     pb.m_degree[mb + i] = deg;
     keys[i] = ((uint32_t)deg << 16) | (uint32_t)i;
   }
