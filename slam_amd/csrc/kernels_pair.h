@@ -885,7 +885,11 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
 // then walks the sorted candidates (8 waves measured best).
 #define CLIQUE_WAVES 8
 __host__ __device__ inline int clique_ctl_ints() { return 4 + SORT_QCAP * 2 + CLIQUE_WAVES * SORT_STACK * 2; }
-__host__ __device__ inline int clique_lds_bytes(int mcap, int cwords) { return mcap * 16 + cwords * 4 + clique_ctl_ints() * 4 + 64; }
+// keys | accepted mask | sort control | scratch: the sort's 12*mcap bytes, reused as the 64 x (cwords+1) staged rows
+__host__ __device__ inline int clique_lds_bytes(int mcap, int cwords) {
+  const int scratch = mcap * 12 > 256 * (cwords + 1) ? mcap * 12 : 256 * (cwords + 1);
+  return mcap * 4 + cwords * 4 + clique_ctl_ints() * 4 + scratch + 64;
+}
 __global__ __launch_bounds__(CLIQUE_WAVES * 64) void k_clique(PairBufs pb) {
   extern __shared__ __align__(16) uint8_t lds[];
   const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x, lane = tid & 63;
@@ -928,23 +932,29 @@ __global__ __launch_bounds__(CLIQUE_WAVES * 64) void k_clique(PairBufs pb) {
   // matrix are first copied into LDS with coalesced loads (the sort scratch is dead by now and is reused); lane k
   // then owns row k: "consistent with every inlier so far" is a word-wise test against the accepted mask, and the
   // 64x64 block of mutual consistency bits resolves the order dependence inside the round without memory traffic.
-  uint32_t* srow = tmp;                 // [64][pitch], aliases tmp/li/ri/ls/le (12*mcap bytes >= 64*pitch*4)
-  const int pitch = nw | 1;             // odd pitch: lane-strided reads are conflict-free
+  uint32_t* srow = tmp;                 // [64][pitch], aliases tmp/li/ri/ls/le (sized by clique_lds_bytes)
+  const int pitch = ((nw + 3) & ~3) | 1;  // whole quads per row, odd pitch: lane-strided reads are conflict-free
   int num_inl = 0;
   bool stop = false;
   // When a row fits one word per lane (N <= 2048) the next round's 64 rows are fetched into registers while the
   // current round is resolved (the candidate order is already fixed by the sort), hiding the HBM/L2 round trip.
   const bool pipelined = nw <= 64;
-  uint32_t pre[64];
+  // a row is read with 16-byte loads by 8 lanes (N <= 1024) or 16 lanes (N <= 2048): 8 or 4 rows per load instruction
+  const int lsh = nw <= 32 ? 3 : 4, lpr = 1 << lsh, rpi = 64 >> lsh;  // lanes per row, rows per instruction; lpr loads per round
+  const int lq = lane & (lpr - 1), lrow = lane >> lsh;
+  uint4 pre[16];
   const uint32_t* __restrict__ cb = pb.cbits + mb * pb.cwords;  // wave-uniform base: rows are addressed with 32-bit offsets
   const uint32_t cw = (uint32_t)pb.cwords;
   auto fetch = [&](int c0) {
     const int mm = c0 + lane;
-    const int idl = (mm < N) ? (int)(keys[mm] & 0xFFFF) : 0;
+    const int idl = (mm < N) ? (int)(keys[mm] & 0xFFFF) : 0;  // lanes past N carry id 0: a harmless in-range row
 #pragma unroll
-    for (int u = 0; u < 64; u++) {
-      const uint32_t idk = (uint32_t)__builtin_amdgcn_readlane(idl, u);
-      pre[u] = (lane < nw) ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(cb) + (idk * cw + (uint32_t)lane) * 4u) : 0u;
+    for (int k = 0; k < 16; k++) {
+      if (k < lpr) {
+        const uint32_t idk = (uint32_t)__shfl(idl, k * rpi + lrow, 64);
+        pre[k] = (4 * lq < nw) ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(cb) + (idk * cw + 4u * (uint32_t)lq) * 4u)
+                               : make_uint4(0u, 0u, 0u, 0u);
+      }
     }
   };
   if (pipelined && !stop) fetch(0);
@@ -956,8 +966,12 @@ __global__ __launch_bounds__(CLIQUE_WAVES * 64) void k_clique(PairBufs pb) {
     const int kmax = min(64, N - c0);
     if (pipelined) {
 #pragma unroll
-      for (int u = 0; u < 64; u++)
-        if (lane < nw) srow[u * pitch + lane] = pre[u];
+      for (int k = 0; k < 16; k++) {
+        if (k < lpr && 4 * lq < nw) {  // words past nw inside the last quad are zero in memory; they land in the row's slack
+          uint32_t* d = srow + (k * rpi + lrow) * pitch + 4 * lq;
+          d[0] = pre[k].x; d[1] = pre[k].y; d[2] = pre[k].z; d[3] = pre[k].w;
+        }
+      }
       wavealgo::wave_lds_sync();
       if (c0 + 64 < N) fetch(c0 + 64);
     } else {
