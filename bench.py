@@ -55,7 +55,7 @@ def algorithmic_bytes(geom: dict, stats: dict) -> dict:
     lv = [(W >> l) * (H >> l) for l in range(L)]
     K, N = stats["mean_kp_per_frame"], stats["mean_matches"]
     B = {}
-    B["ingest"] = nf * (2 * W * H)  # rvo_match_frames_dev copies gray only; depth is sampled in place
+    B["ingest"] = nf * 16  # rvo_match_frames_dev reads gray and depth in place: the launch records two pointers per slot
     B["pyr_down"] = nf * sum(lv[l - 1] + lv[l] for l in range(1, L)) / max(1, L - 1)
     B["fast_grid"] = nf * (sum(lv) + geom["total_buckets"] * (geom["max_per"] * 4 + 8))
     B["build_keypoints"] = nf * (geom["total_buckets"] * (geom["max_per"] * 4 + 8) + K * (36 + 8 + 4 + 2 + 8))

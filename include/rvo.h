@@ -137,9 +137,10 @@ int rvo_match_pairs_async(rvo_ctx* ctx, int n, const int32_t* ref_slots, const i
  * work area i estimates slots[2i] -> slots[2i+1] exactly as rvo_match_pairs_async does.  The batch is cut into
  * chunks that run the whole frame+pair pipeline on separate HIP streams, so the latency-bound pair stages of one
  * chunk overlap the throughput-bound frame stages of another.  Enqueues only; results via rvo_get_pair_results.
- * The gray images are copied into the slots; the depth images are NOT: they are sampled in place (a few KB per
- * frame), so depth_dev must stay valid and unchanged for as long as these slots are used (until they are prepared
- * again), e.g. by a later rvo_match_pairs that names them. */
+ * Nothing is copied when the images already have the slot layout (width % 16 == 0, 16-byte aligned buffers): the
+ * level-0 image and the depth image (sampled at a few thousand pixels) are read in place, so gray_dev and depth_dev
+ * must stay valid and unchanged for as long as these slots are used (until they are prepared again), e.g. by a
+ * later rvo_match_pairs that names them.  rvo_prepare_frames[_dev] and the stream entry points always copy. */
 int rvo_match_frames_dev(rvo_ctx* ctx, int n, const uint8_t* gray_dev, const uint16_t* depth_dev, const int32_t* fast_thr,
                          const int32_t* slots, const double* init_pose);
 

@@ -71,7 +71,7 @@ __device__ inline int block_excl_scan(int v, int* s_wave, int* total) {
 // (depth is only sampled at keypoints and refined matches, ~5 KB of the 614 KB image).
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_ingest(FrameBufs fb, FrameGeom g, const uint8_t* __restrict__ gray,
-                                                const uint16_t* __restrict__ depth, const int32_t* __restrict__ slots, int copy_depth) {
+                                                const uint16_t* __restrict__ depth, const int32_t* __restrict__ slots, int copy_depth, int copy_gray) {
   const int f = blockIdx.y;
   const int slot = slots[f];
   if (slot < 0) return;
@@ -81,18 +81,23 @@ __global__ __launch_bounds__(256) void k_ingest(FrameBufs fb, FrameGeom g, const
   uint8_t* gd = fb.img + (size_t)slot * g.img_bytes + g.lv[0].img_off;
   uint16_t* dd = fb.depth + (size_t)slot * ndp;
   const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
-  if (tid == 0) fb.depth_tab[slot] = copy_depth ? dd : dsrc;
+  if (tid == 0) {
+    fb.depth_tab[slot] = copy_depth ? dd : dsrc;
+    fb.l0_tab[slot] = copy_gray ? gd : gs;
+  }
   if (VEC) {
     const int cpr = g.W / 16, spr = g.lv[0].stride / 16;
     const uint4* s4 = reinterpret_cast<const uint4*>(gs);
     uint4* d4 = reinterpret_cast<uint4*>(gd);
-    for (int i = tid; i < cpr * g.H; i += nth) d4[(i / cpr) * spr + i % cpr] = s4[i];
+    if (copy_gray)
+      for (int i = tid; i < cpr * g.H; i += nth) d4[(i / cpr) * spr + i % cpr] = s4[i];
     const uint4* ds4 = reinterpret_cast<const uint4*>(dsrc);
     uint4* dd4 = reinterpret_cast<uint4*>(dd);
     if (copy_depth)
       for (int i = tid; i < (int)(ndp / 8); i += nth) dd4[i] = ds4[i];
   } else {
-    for (int i = tid; i < (int)npx; i += nth) gd[(size_t)(i / g.W) * g.lv[0].stride + i % g.W] = gs[i];
+    if (copy_gray)
+      for (int i = tid; i < (int)npx; i += nth) gd[(size_t)(i / g.W) * g.lv[0].stride + i % g.W] = gs[i];
     if (copy_depth)
       for (int i = tid; i < (int)ndp; i += nth) dd[i] = dsrc[i];
   }
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
   const LevelGeom S = g.lv[lvl - 1], D = g.lv[lvl];
   const int slot = slots[blockIdx.z];
   if (slot < 0) return;  // stream still in warm-up (vo.cpp:58-69)
-  const uint8_t* __restrict__ src = fb.img + (size_t)slot * g.img_bytes + S.img_off;
+  const uint8_t* __restrict__ src = level_img(fb, g, slot, lvl - 1);
   uint8_t* __restrict__ dst = fb.img + (size_t)slot * g.img_bytes + D.img_off;
   const int dw = S.w / 2, dh = S.h / 2;
   const int ox0 = blockIdx.x * PYR_TW, oy0 = blockIdx.y * PYR_TH;
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   const int bi = gb - G.bucket_off;
   const int cx0 = (bi % G.gcols) * g.gw, cy0 = (bi / G.gcols) * g.gh;
   const int cw = min(g.gw, G.w - cx0), ch = min(g.gh, G.h - cy0);
-  const uint8_t* __restrict__ img = fb.img + (size_t)slot * g.img_bytes + G.img_off;
+  const uint8_t* __restrict__ img = level_img(fb, g, slot, lvl);
   const int TP = L.tile_pitch, SP = L.score_pitch;
 
   // ---- stage cell + 4 px halo with 16-byte loads: the tile starts at the 16-aligned column at or left of cx0-4
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(256) void k_descriptors(FrameBufs fb, FrameGeom g, 
       if (l < g.levels && idx >= g.lv[l].kp_off) lvl = l;
     const LevelGeom& G = g.lv[lvl];
     if (idx - G.kp_off >= fb.kp_cnt[slot * RVO_MAX_LEVELS + lvl]) continue;  // uniform within the 16-lane group
-    const uint8_t* __restrict__ img = fb.img + (size_t)slot * g.img_bytes + G.img_off;
+    const uint8_t* __restrict__ img = level_img(fb, g, slot, lvl);
     const size_t kidx = (size_t)slot * g.kp_total + idx;
     const uint32_t k = fb.kp_uvs[kidx];
     const uint8_t* c = img + (size_t)kp_y(k) * G.stride + kp_x(k);

@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void k_init_rotation(FrameBufs fb, FrameGeom g
   float* warped = tdy + npx;
   double* s_red = reinterpret_cast<double*>(lds + (((size_t)5 * npx * 4 + 15) & ~(size_t)15));
 
-  const uint8_t* rimg = fb.img + (size_t)pb.rot_slot[pair] * g.img_bytes + G.img_off;
-  const uint8_t* timg = fb.img + (size_t)pb.tgt_slot[pair] * g.img_bytes + G.img_off;
+  const uint8_t* rimg = level_img(fb, g, pb.rot_slot[pair], pyr);
+  const uint8_t* timg = level_img(fb, g, pb.tgt_slot[pair], pyr);
   // grayToEigen, motion_estimate.cpp:1338-1367 (box sums are exact in float)
   const int f = 1 << ds;
   const double pf2 = (double)f * (double)f;
@@ -570,8 +570,8 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
   const int t = pb.lm_tgt[(size_t)pair * g.kp_total + G.kp_off + j];
   const size_t rk = (size_t)rs * g.kp_total + G.kp_off + r, tk = (size_t)ts * g.kp_total + G.kp_off + t;
   const uint32_t rkp = fb.kp_uvs[rk], tkp = fb.kp_uvs[tk];
-  const uint8_t* __restrict__ rg = fb.img + (size_t)rs * g.img_bytes + G.img_off;
-  const uint8_t* __restrict__ tg = fb.img + (size_t)ts * g.img_bytes + G.img_off;
+  const uint8_t* __restrict__ rg = level_img(fb, g, rs, lvl);
+  const uint8_t* __restrict__ tg = level_img(fb, g, ts, lvl);
   const int S = G.stride;
 
   // ---- refineFeatureMatch, motion_estimate.cpp:757-900 (descriptors recomputed per pass instead of stored)

@@ -272,6 +272,7 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   rc |= dalloc(c, &fb.img, F * g.img_bytes);
   rc |= dalloc(c, &fb.depth, F * g.Wd * g.Hd);
   rc |= dalloc(c, &fb.depth_tab, F);
+  rc |= dalloc(c, &fb.l0_tab, F);
   rc |= dalloc(c, &fb.bk_cnt, F * g.total_buckets);
   rc |= dalloc(c, &fb.bk_det, F * g.total_buckets);
   rc |= dalloc(c, &fb.bk_kp, F * g.total_buckets * g.max_per);
@@ -292,6 +293,9 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
     std::vector<const uint16_t*> tab(F);
     for (size_t i = 0; i < F; i++) tab[i] = fb.depth + i * (size_t)g.Wd * g.Hd;
     HIPCHK(hipMemcpy(fb.depth_tab, tab.data(), F * sizeof(tab[0]), hipMemcpyHostToDevice));
+    std::vector<const uint8_t*> itab(F);
+    for (size_t i = 0; i < F; i++) itab[i] = fb.img + i * (size_t)g.img_bytes + g.lv[0].img_off;
+    HIPCHK(hipMemcpy(fb.l0_tab, itab.data(), F * sizeof(itab[0]), hipMemcpyHostToDevice));
   }
   HIPCHK(hipMemset(fb.kp_cnt, 0, F * RVO_MAX_LEVELS * 4));
   HIPCHK(hipMemset(fb.det_cnt, 0, F * RVO_MAX_LEVELS * 4));
@@ -359,12 +363,17 @@ static int ensure_stage(rvo_ctx* c, int n) {
   return RVO_OK;
 }
 
+// copy = 1: level-0 image and raw depth are copied into the slots.  copy = 0 (rvo_match_frames_dev): depth is always
+// read in place; the gray image too when its rows already have the level-0 stride and 16-byte alignment, and then
+// the launch only records the two pointers per slot.
 static int launch_ingest_on(rvo_ctx* c, hipStream_t st, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots,
-                            int copy_depth) {
+                            int copy) {
   const FrameGeom& g = c->g;
   const bool vec = (g.W % 16 == 0) && (((size_t)g.Wd * g.Hd) % 8 == 0) && (((uintptr_t)gray & 15) == 0) && (((uintptr_t)depth & 15) == 0);
-  if (vec) LAUNCH_ON(c, st, "ingest", k_ingest<true>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots, copy_depth);
-  else LAUNCH_ON(c, st, "ingest", k_ingest<false>, dim3(16, n), dim3(256), 0, c->fb, g, gray, depth, d_slots, copy_depth);
+  const int copy_gray = (copy || g.lv[0].stride != g.W || ((uintptr_t)gray & 15) != 0) ? 1 : 0;
+  const dim3 grid(copy_gray ? 16 : 1, n);
+  if (vec) LAUNCH_ON(c, st, "ingest", k_ingest<true>, grid, dim3(256), 0, c->fb, g, gray, depth, d_slots, copy, copy_gray);
+  else LAUNCH_ON(c, st, "ingest", k_ingest<false>, grid, dim3(256), 0, c->fb, g, gray, depth, d_slots, copy, copy_gray);
   return RVO_OK;
 }
 static int launch_ingest(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots) {
@@ -448,7 +457,9 @@ int rvo_get_level_image(rvo_ctx* c, int slot, int level, uint8_t* out) {
   if (check_slot_level(c, slot, level) || !out) return RVO_E_INVALID;
   HIPCHK(hipStreamSynchronize(c->stream));
   const LevelGeom& L = c->g.lv[level];
-  HIPCHK(hipMemcpy(out, c->fb.img + (size_t)slot * c->g.img_bytes + L.img_off, (size_t)L.stride * L.h, hipMemcpyDeviceToHost));
+  const uint8_t* src = c->fb.img + (size_t)slot * c->g.img_bytes + L.img_off;
+  if (level == 0) HIPCHK(hipMemcpy(&src, c->fb.l0_tab + slot, sizeof(src), hipMemcpyDeviceToHost));  // may live in caller memory
+  HIPCHK(hipMemcpy(out, src, (size_t)L.stride * L.h, hipMemcpyDeviceToHost));
   return RVO_OK;
 }
 

@@ -41,6 +41,8 @@ __host__ __device__ inline int kp_s(uint32_t k) { return k >> 22; }
 struct FrameBufs {
   uint8_t* img;       // [slots][img_bytes]
   uint16_t* depth;    // [slots][Wd*Hd] raw millimetres, 0 = invalid (vo.cpp:83-87 conversion is done lazily)
+  const uint8_t** l0_tab;      // [slots] where the slot's level-0 image lives (stride = lv[0].stride): its block of `img`, or
+                               // (rvo_match_frames_dev, W % 16 == 0) the caller's device buffer, read in place
   const uint16_t** depth_tab;  // [slots] where the slot's depth image lives: its block of `depth`, or (rvo_match_frames_dev)
                                // the caller's device buffer, read in place
   int32_t* bk_cnt;    // [slots][total_buckets] kept per bucket (<= max_per)
@@ -87,6 +89,11 @@ struct PairBufs {
   int mcap, cwords;
   int pair0;           // first pair work area of this launch (chunks of a batch run on different HIP streams)
 };
+
+// image of pyramid level `lvl` of a slot
+__device__ inline const uint8_t* level_img(const FrameBufs& fb, const FrameGeom& g, int slot, int lvl) {
+  return lvl == 0 ? fb.l0_tab[slot] : fb.img + (size_t)slot * g.img_bytes + g.lv[lvl].img_off;
+}
 
 struct CamParams {
   double fx, fy, cx, cy;  // rectified camera (camera.cpp:7-12)
