@@ -79,6 +79,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
 
+    # stdout carries exactly one JSON line: library banners (gloo, RCCL, HIP) that print to fd 1 are sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -230,7 +235,7 @@ def main():
                     cpu_baseline=cpu, kernels=kernels, stats=stats,
                     check=dict(pairs_success=ok, max_abs_pose_err_vs_truth=float(err)),
                     gather_ms=gather_ms, gather_backend=gather_backend)
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
