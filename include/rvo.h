@@ -107,6 +107,10 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* params, int device,
 void rvo_destroy(rvo_ctx* ctx);
 const char* rvo_last_error(void);
 
+/* Tuning knob without a counterpart in the reference: into how many chunks a batch is cut (each chunk runs on its own
+ * HIP stream, see rvo_match_frames_dev).  Default 2 (env RVO_PAIR_CHUNKS overrides at rvo_create).  Use 1 when the
+ * caller already keeps two batches in flight on two contexts (double buffering), which overlaps better. */
+int rvo_set_pair_chunks(rvo_ctx* ctx, int chunks);
 /* Use an existing HIP stream (hipStream_t passed as void*; NULL = the context's own). */
 int rvo_set_stream(rvo_ctx* ctx, void* hip_stream);
 int rvo_sync(rvo_ctx* ctx);

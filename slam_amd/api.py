@@ -147,6 +147,9 @@ class Context:
         self._chk(self.L.rvo_depth_to_point_cloud_dev(self.h, n, C.c_void_p(depth_ptr), float(x_to_z), float(y_to_z),
                                                       C.c_void_p(cloud_ptr)))
 
+    def set_pair_chunks(self, chunks: int):
+        self._chk(self.L.rvo_set_pair_chunks(self.h, chunks))
+
     def pair_information(self, n):
         """info = cov.inverse() of the first n pair results (pose_graph.cpp:265), [n, 6, 6]; zeros where not SUCCESS."""
         out = np.zeros((n, 6, 6))

@@ -344,6 +344,12 @@ int rvo_set_stream(rvo_ctx* c, void* s) {
   return RVO_OK;
 }
 
+int rvo_set_pair_chunks(rvo_ctx* c, int chunks) {
+  if (!c || chunks < 1 || chunks > rvo_ctx::kAux + 1) { g_err = "rvo_set_pair_chunks: 1..4"; return RVO_E_INVALID; }
+  c->pair_chunks = chunks;
+  return RVO_OK;
+}
+
 int rvo_sync(rvo_ctx* c) {
   if (!c) return RVO_E_INVALID;
   HIPCHK(hipStreamSynchronize(c->stream));
