@@ -25,24 +25,36 @@ if __name__ == "__main__":
     depth = np.stack([np.stack([seqs[s % len(seqs)][t][1] for s in range(S)]) for t in range(T)])
     dg = torch.from_numpy(gray).cuda(); dd = torch.from_numpy(depth.view(np.int16)).cuda()
     p = default_params(); p.warmup_frames = 1
-    ctx = Context(intr, p, max_frames=3 * S, max_pairs=S)
-    ctx.streams_reset(S)
+    # the streams are split over NC contexts (own HIP streams each): the latency-bound pair stages of one group of
+    # streams overlap the frame stages of the other
+    NC = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    per = S // NC
+    ctxs = [Context(intr, p, max_frames=3 * per, max_pairs=per) for _ in range(NC)]
+    for c in ctxs:
+        c.streams_reset(per)
+        c.set_pair_chunks(1)
+    torch.cuda.synchronize()
     order = list(range(T)) + list(range(T - 2, 0, -1))
     def step(k):
         t = order[k % len(order)]
-        ctx.stream_step_dev(dg[t].data_ptr(), dd[t].data_ptr(), S)
+        for i, c in enumerate(ctxs):
+            c.stream_step_dev(dg[t, i * per:].data_ptr(), dd[t, i * per:].data_ptr(), per)
     for k in range(6): step(k)
-    ctx.sync()
-    ctx.profile_enable(True)
+    for c in ctxs: c.sync()
+    for c in ctxs: c.profile_enable(True)
     n = 30
     t0 = time.perf_counter()
     for k in range(6, 6 + n): step(k)
-    ctx.sync()
+    for c in ctxs: c.sync()
     dt = time.perf_counter() - t0
-    prof = ctx.profile_read()
-    res = ctx.stream_results(S)
+    prof = {}
+    for c in ctxs:
+        for name, v in c.profile_read().items():
+            a = prof.setdefault(name, dict(total_ms=0.0, calls=0)); a["total_ms"] += v["total_ms"]; a["calls"] += v["calls"]
+    res = [r for c in ctxs for r in c.stream_results(per)]
+    S = per * NC
     ok = sum(r["status"] == 1 for r in res)
-    print(f"streams={S} ms/step={dt / n * 1e3:.3f} frames/s={S * n / dt:.0f} last-step success={ok}/{S} "
+    print(f"contexts={NC} streams={S} ms/step={dt / n * 1e3:.3f} frames/s={S * n / dt:.0f} last-step success={ok}/{S} "
           f"mean inliers={np.mean([r['num_inliers'] for r in res]):.0f} fallbacks={sum(r['used_fallback'] for r in res)}")
     print({k: (round(v["total_ms"] / n, 3), v["calls"] // n) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])})
     print("mean matches", np.mean([r["num_matches"] for r in res]))
