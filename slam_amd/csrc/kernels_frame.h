@@ -245,6 +245,7 @@ __device__ inline uint32_t compass2(uint32_t p, uint32_t n, uint32_t s, uint32_t
 
 struct FastLds {  // byte offsets into dynamic LDS, computed on the host (all multiples of 4)
   int tile_pitch, score_pitch;
+  int cand_cap;  // phase-A candidate queue entries (u16)
   int off_score, off_list, off_misc;
   int list_cap;
   int total;
@@ -279,19 +280,27 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   const uint8_t* __restrict__ img = level_img(fb, g, slot, lvl);
   const int TP = L.tile_pitch, SP = L.score_pitch;
 
-  // ---- stage cell + 4 px halo with 16-byte loads: the tile starts at the 16-aligned column at or left of cx0-4
-  // (shx = columns between the two), rows are TP = multiple-of-16 bytes.  Index walkers avoid integer division.
-  const int trows = ch + 8, t16 = TP / 16;
+  // ---- stage cell + 4 px halo: 16-byte global loads from the 16-aligned column at or left of cx0-4, stored as dwords
+  // into compact LDS rows of TP bytes whose column shl (= 0 when cells start on multiples of 4) is image column
+  // cx0-4.  LDS per workgroup decides how many workgroups share a CU (measured: 4 -> 5 per CU is 13 % faster).
+  const int trows = ch + 8;
   const int gx0 = (cx0 - 4) & ~15, gy0 = cy0 - 4;
-  const int shx = cx0 - 4 - gx0;
+  const int shx = cx0 - 4 - gx0;      // 0..15: columns between the first loaded byte and the tile's first column
+  const int shl = shx & 3, sd = shx >> 2, tdw = TP / 4;
   {
+    const int t16 = (shx + cw + 8 + 15) >> 4;  // 16-byte words per row
     const int q = 256 / t16, rr = 256 % t16;
     int r = tid / t16, c = tid % t16;
     while (r < trows) {
       const int gy = gy0 + r, gx = gx0 + 16 * c;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (gy >= 0 && gy < G.h && gx >= 0 && gx < G.stride) v = *reinterpret_cast<const uint4*>(img + (size_t)gy * G.stride + gx);
-      *reinterpret_cast<uint4*>(s_tile + r * TP + 16 * c) = v;
+      uint32_t* drow = reinterpret_cast<uint32_t*>(s_tile + r * TP);
+      const int d0 = 4 * c - sd;
+      if (d0 >= 0 && d0 < tdw) drow[d0] = v.x;
+      if (d0 + 1 >= 0 && d0 + 1 < tdw) drow[d0 + 1] = v.y;
+      if (d0 + 2 >= 0 && d0 + 2 < tdw) drow[d0 + 2] = v.z;
+      if (d0 + 3 >= 0 && d0 + 3 < tdw) drow[d0 + 3] = v.w;
       c += rr; r += q;
       if (c >= t16) { c -= t16; r++; }
     }
@@ -304,10 +313,11 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   const int sw = cw + 2, sh = ch + 2;
   uint16_t* s_cand = reinterpret_cast<uint16_t*>(s_list);  // aliases the survivor list (used after later barriers)
   int* s_ncand = s_misc + 8;
+  int* s_over = s_misc + 9;  // the candidate queue (L.cand_cap entries, half of the pixels) overflowed: dense fallback
   uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_misc + 16);  // NMS survivor bitmap, one bit per cell pixel (raster)
   const int P = cw * ch;
   const int nwords = (P + 31) >> 5;
-  if (tid == 0) *s_ncand = 0;
+  if (tid == 0) { *s_ncand = 0; *s_over = 0; }
   for (int w = tid; w < nwords; w += 256) s_bits[w] = 0;
   for (int w = tid; w < (L.off_list - L.off_score) / 4; w += 256) reinterpret_cast<uint32_t*>(s_score)[w] = 0;
   __syncthreads();
@@ -315,10 +325,10 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   {
     // 4 horizontally adjacent pixels per iteration: 5 aligned LDS dwords (centre, left, right, 3 rows up, 3 rows down)
     // feed two packed-u16 evaluations (even / odd bytes).  Group j of score row sy covers tile x = 4j..4j+3.
-    const int jlo = (shx + 3) >> 2, ngr = ((shx + sw + 2) >> 2) - jlo + 1;  // score column sx sits at tile x = sx + 3 + shx
+    const int jlo = (shl + 3) >> 2, ngr = ((shl + sw + 2) >> 2) - jlo + 1;  // score column sx sits at tile x = sx + 3 + shl
     const int q = 256 / ngr, rr = 256 % ngr;
     const int gsy0 = tid / ngr, gj0 = jlo + tid % ngr;
-    const int txlo = max(3, 7 - cx0) + shx, txhi = min(sw + 2, G.w - cx0) + shx;  // fast9Detect loop bounds, feature.cpp:3042-3043
+    const int txlo = max(3, 7 - cx0) + shl, txhi = min(sw + 2, G.w - cx0) + shl;  // fast9Detect loop bounds, feature.cpp:3042-3043
     const uint32_t b2 = (uint32_t)b | ((uint32_t)b << 16);
     unsigned long long mask = 0;
     int sy = gsy0, j = gj0;
@@ -351,14 +361,17 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     const int wtot = __shfl(inc, 63, 64);
     int base = 0;
     if (lane == 0 && wtot) base = atomicAdd(s_ncand, wtot);
-    base = __shfl(base, 0, 64) + inc - mine;
+    base = __shfl(base, 0, 64);
+    const bool fits = base + wtot <= L.cand_cap;  // wave-uniform
+    if (!fits && lane == 0) *s_over = 1;
+    base += inc - mine;
     sy = gsy0; j = gj0;
-    for (int k = 0; k < 16 && (mask >> (4 * k)); k++) {
+    for (int k = 0; fits && k < 16 && (mask >> (4 * k)); k++) {
       uint32_t bits = (uint32_t)(mask >> (4 * k)) & 0xFu;
       while (bits) {
         const int i = __ffs(bits) - 1;
         bits &= bits - 1;
-        s_cand[base++] = (uint16_t)((sy << 8) | (4 * j + i - 3 - shx));
+        s_cand[base++] = (uint16_t)((sy << 8) | (4 * j + i - 3 - shl));
       }
       j += rr; sy += q;
       if (j >= jlo + ngr) { j -= ngr; sy++; }
@@ -367,35 +380,50 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   __syncthreads();
   // ---- phase B: score A = fast9CornerScore + 1 for every queued pixel; it is a corner iff A > b (the segment
   // test passes at threshold b iff b < A).  All lanes busy; measured faster than a separate detect pass.
-  const int ncand = *s_ncand;
+  const bool over = *s_over != 0;
+  const int ncand = over ? 0 : *s_ncand;
   for (int c = tid; c < ncand; c += 256) {
     const uint16_t v = s_cand[c];
     const int sy = v >> 8, sx = v & 255;
     int d[16];
-    fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3 + shx), TP, d);
+    fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3 + shl), TP, d);
     const int A = fast9_A(d);
     if (A > b) s_score[sy * SP + sx] = (uint8_t)A;
   }
+  if (over) {  // more than half of the pixels passed the compass test (dense noise): score every pixel
+    for (int i = tid; i < sw * sh; i += 256) {
+      const int sy = i / sw, sx = i - sy * sw;
+      const int gx = cx0 + sx - 1, gy = cy0 + sy - 1;
+      if (gx < 3 || gx > G.w - 4 || gy < 3 || gy > G.h - 4) continue;  // fast9Detect loop bounds, feature.cpp:3042-3043
+      int d[16];
+      fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3 + shl), TP, d);
+      const int A = fast9_A(d);
+      if (A > b) s_score[sy * SP + sx] = (uint8_t)A;
+    }
+  }
   __syncthreads();
-  const int nlist = ncand;
-  const uint16_t* s_qlist = s_cand;
 
   // ---- NMS (feature.cpp:5960-6056: a corner survives iff no 8-neighbour corner has score >= its own) on the
-  // queued pixels only; survivors set one bit of a raster-ordered bitmap of the cell.
-  for (int c = tid; c < nlist; c += 256) {
-    const uint16_t v = s_qlist[c];
-    const int sy = v >> 8, sx = v & 255;
-    if (sx < 1 || sx > cw || sy < 1 || sy > ch) continue;  // halo pixels belong to neighbouring buckets
+  // queued pixels only (all cell pixels in the dense fallback); survivors set one bit of a raster-ordered bitmap.
+  auto nms = [&](int sy, int sx) {
     const uint8_t* cc = s_score + sy * SP + sx;
     const int sc = cc[0];
-    if (sc == 0) continue;
+    if (sc == 0) return;
     const bool sup = cc[-1] >= sc || cc[1] >= sc || cc[-SP - 1] >= sc || cc[-SP] >= sc || cc[-SP + 1] >= sc ||
                      cc[SP - 1] >= sc || cc[SP] >= sc || cc[SP + 1] >= sc;
     if (!sup) {
       const int idx = (sy - 1) * cw + (sx - 1);
       atomicOr(&s_bits[idx >> 5], 1u << (idx & 31));
     }
+  };
+  for (int c = tid; c < ncand; c += 256) {
+    const uint16_t v = s_cand[c];
+    const int sy = v >> 8, sx = v & 255;
+    if (sx < 1 || sx > cw || sy < 1 || sy > ch) continue;  // halo pixels belong to neighbouring buckets
+    nms(sy, sx);
   }
+  if (over)
+    for (int i = tid; i < P; i += 256) nms(i / cw + 1, i % cw + 1);
   __syncthreads();
   // ---- raster-ordered compaction of the bitmap (the order the reference pushes keypoints into the bucket)
   int total = 0, base_run = 0;

@@ -239,13 +239,15 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   }
   // FAST workgroup LDS carve-up
   FastLds& fl = c->fl;
-  fl.tile_pitch = round_up(g.gw + 8 + 15, 16);  // the tile starts on a 16-byte boundary at or left of the halo
+  fl.tile_pitch = round_up(g.gw + 8 + (g.gw % 4 ? 3 : 0), 4);  // compact rows; +3 when cells do not start on multiples of 4
   fl.score_pitch = round_up(g.gw + 2, 4);
   fl.off_score = round_up(fl.tile_pitch * (g.gh + 8), 16);
   fl.off_list = fl.off_score + round_up(fl.score_pitch * (g.gh + 2), 16);
   fl.list_cap = ((g.gw + 1) / 2) * ((g.gh + 1) / 2) + 1;
-  // the same region first holds the phase-A candidate queue: u16 per pixel of the (gw+2)x(gh+2) score region
-  fl.off_misc = fl.off_list + round_up(std::max(fl.list_cap * 4, (g.gw + 2) * (g.gh + 2) * 2 + 4), 16);
+  // the same region first holds the phase-A candidate queue (u16 per entry): room for half of the pixels of the
+  // (gw+2)x(gh+2) score region (k_fast_grid falls back to a dense pass beyond that), at least the list's bytes
+  fl.cand_cap = std::max(fl.list_cap * 2, ((g.gw + 2) * (g.gh + 2) + 1) / 2);
+  fl.off_misc = fl.off_list + round_up(fl.cand_cap * 2, 16);
   fl.total = fl.off_misc + 64 + round_up((g.gw * g.gh + 31) / 32 * 4, 16);
   if (fl.total > 150 * 1024 || g.gw + 2 > 255 || g.gh + 2 > 255 || (g.gw + 2) * (g.gh + 2) > 64 * 256 ||
       ((g.gw + 7) / 4 + 1) * (g.gh + 2) > 16 * 256) {  // phase A of k_fast_grid: <= 16 four-pixel groups per thread

@@ -40,8 +40,10 @@ def test_prepare_frame_640(scene, intr640, thr):
     ctx.close()
 
 
-def test_prepare_frame_noise_overflowing_buckets(intr640):
-    """Dense noise: every bucket overflows max-keypoints-per-grid, so the nth_element replay decides the sets."""
+@pytest.mark.parametrize("thr", [5, 20])
+def test_prepare_frame_noise_overflowing_buckets(intr640, thr):
+    """Dense noise: every bucket overflows max-keypoints-per-grid, so the nth_element replay decides the sets; more than
+    half of the pixels pass FAST's compass pre-test, so k_fast_grid's candidate queue overflows into its dense pass."""
     from oracle.pyoracle import Oracle
     from slam_amd.api import Context
     rng = np.random.default_rng(0)
@@ -50,8 +52,8 @@ def test_prepare_frame_noise_overflowing_buckets(intr640):
     d[rng.random((480, 640)) < 0.3] = 0
     ctx = Context(intr640, max_frames=1, max_pairs=1)
     orc = Oracle(intr640)
-    ctx.prepare_frames(g[None], d[None], 20, [0])
-    orc.prepare(0, g, d, 20)
+    ctx.prepare_frames(g[None], d[None], thr, [0])
+    orc.prepare(0, g, d, thr)
     assert orc.level_info(0, 0)["num_detected"] > 5000
     _compare_frame(ctx, orc, 0, 0, 3)
     ctx.close()
