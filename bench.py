@@ -57,9 +57,9 @@ def algorithmic_bytes(geom: dict, stats: dict) -> dict:
     B = {}
     B["ingest"] = nf * 16  # rvo_match_frames_dev reads gray and depth in place: the launch records two pointers per slot
     B["pyr_down"] = nf * sum(lv[l - 1] + lv[l] for l in range(1, L)) / max(1, L - 1)
-    B["fast_grid"] = nf * (sum(lv) + geom["total_buckets"] * (geom["max_per"] * 4 + 8))
+    B["fast_grid"] = nf * (sum(lv) + geom["total_buckets"] * (geom["max_per"] * (4 + 80) + 8))
     B["build_keypoints"] = nf * (geom["total_buckets"] * (geom["max_per"] * 4 + 8) + K * (36 + 8 + 4 + 2 + 8))
-    B["descriptors"] = nf * K * (4 + 81 + 80)
+    B["descriptors"] = nf * K * (2 + 80 + 80)
     B["init_rotation"] = npair * 2 * lv[L - 1]
     B["match"] = npair * (2 * K * 80 + 2 * K * 32 + N * 8)
     B["refine"] = npair * N * (2 * 100 + 120)

@@ -229,6 +229,14 @@ __device__ inline int fast9_A(const int* d) {
   return max(best_lo, -best_hi);
 }
 
+__device__ inline int sum16(int v) {  // 16 lanes = one DPP row: quad permutes, then half-row and row mirrors
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+  return v;
+}
+
 // compass test of phase A on two pixels held in the u16 halves of each operand: corner candidates need
 // min(max(n,s), max(e,w)) > p + b  or  max(min(n,s), min(e,w)) < p - b.  Non-zero half = pass.
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
@@ -448,17 +456,46 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   // ---- GridKeyPointFilter::Filter for this bucket (pyramid.cpp:38-50)
   const int n = min(total, L.list_cap);
   const int maxp = g.max_per;
-  if (n > maxp && tid < 64) {  // wave 0 replays std::nth_element; the image tile is dead by now and serves as scratch
-    uint16_t* li = reinterpret_cast<uint16_t*>(s_tile);
+  if (n > maxp && tid < 64) {  // wave 0 replays std::nth_element; the score tile is dead by now and serves as scratch
+    uint16_t* li = reinterpret_cast<uint16_t*>(s_score);
     wavealgo::wave_nth_element<22>(s_list, maxp, n, li, li + L.list_cap);
   }
   __syncthreads();
   const int keep = min(n, maxp);
-  uint32_t* out = fb.bk_kp + ((size_t)slot * g.total_buckets + gb) * maxp;
+  const size_t bslot = ((size_t)slot * g.total_buckets + gb) * maxp;
+  uint32_t* out = fb.bk_kp + bslot;
   for (int i = tid; i < keep; i += 256) out[i] = s_list[i];
   if (tid == 0) {
     fb.bk_cnt[(size_t)slot * g.total_buckets + gb] = keep;
     fb.bk_det[(size_t)slot * g.total_buckets + gb] = total;
+  }
+  // ---- descriptors of the kept keypoints (ExtractAlignedDescriptor + Normalized twice, feature.cpp:6140-6156,
+  // 6193-6207) straight from the LDS tile: the 9x9 window of a keypoint of this cell lies inside the cell + 4 px halo.
+  // 16 lanes per keypoint; lane l owns descriptor dword l (taps 4l..4l+3), lanes 0-3 also dwords 16-19.
+  {
+    const int sub = tid & 15, grp = tid >> 4;
+    const bool two = sub < (RVO_DESC_LEN - 64) / 4;
+    for (int i = grp; i < keep; i += 16) {
+      const uint32_t k = s_list[i];
+      const uint8_t* c = s_tile + (kp_y(k) - cy0 + 4) * TP + (kp_x(k) - cx0 + 4 + shl);
+      int v[8];
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int t = (m < 4 ? 4 * sub : 64 + 4 * sub) + (m & 3);
+        v[m] = (m < 4 || two) ? (int)c[(t / 9 - 4) * TP + (t % 9 - 4)] : 0;
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; pass++) {
+        const int mean = sum16(v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]) / RVO_DESC_LEN;
+        const int o = 128 - mean;  // mean < 128: add and clamp at 255; mean > 128: subtract and clamp at 0
+#pragma unroll
+        for (int m = 0; m < 8; m++) v[m] = min(255, max(0, v[m] + o));
+        if (!two) { v[4] = v[5] = v[6] = v[7] = 0; }
+      }
+      uint32_t* dsc = reinterpret_cast<uint32_t*>(fb.bk_desc + (bslot + i) * RVO_DESC_LEN);
+      dsc[sub] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+      if (two) dsc[16 + sub] = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
+    }
   }
 }
 
@@ -530,6 +567,7 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
     const int pos = base + block_excl_scan_256(flag, s_wave, &total);
     if (flag) {
       fb.kp_uvs[kbase + pos] = k;
+      fb.kp_src[kbase + pos] = (uint16_t)s;
       fb.kp_rect[kbase + pos] = make_float2(ru, rv);
       double* xyz = fb.kp_xyz + (kbase + pos) * 3;
       xyz[0] = X; xyz[1] = Y; xyz[2] = Z;
@@ -539,59 +577,23 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
   if (tid == 0) fb.kp_cnt[slot * RVO_MAX_LEVELS + lvl] = base;
 }
 
-// Descriptors (ExtractAlignedDescriptor + Normalized twice, feature.cpp:6140-6156, 6193-6207).
-// grid (ceil(kp_total/DESC_PER_BLOCK), n_frames), 256 threads = 16 groups of 16 lanes; a group extracts one
-// keypoint per round.  Lane l owns descriptor dword l (taps 4l..4l+3); lanes 0-3 also own dwords 16-19, so every
-// store is one aligned dword.  Runs after k_build_keypoints (reads kp_uvs / kp_cnt).
-#define DESC_PER_BLOCK 32
-__device__ inline int sum16(int v) {  // 16 lanes = one DPP row: quad permutes, then half-row and row mirrors
-  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
-  return v;
-}
+// Descriptors of the keypoints that survived the border / LUT / depth filter: their rows of bk_desc (written by
+// k_fast_grid) are copied into the level's compact order.  grid (ceil(kp_total*5/256), n_frames): one 16-byte piece
+// per thread, five consecutive threads per keypoint.  Runs after k_build_keypoints (reads kp_src / kp_cnt).
 __global__ __launch_bounds__(256) void k_descriptors(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots) {
   const int slot = slots[blockIdx.y];
   if (slot < 0) return;
-  const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
-  // tap offsets of this lane (row-major over the 9x9 window, last pixel dropped)
-  int oy[8], ox[8];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int idx = t / 5, piece = t - idx * 5;  // keypoint slot within the frame
+  if (idx >= g.kp_total) return;
+  int lvl = 0;
 #pragma unroll
-  for (int m = 0; m < 8; m++) {
-    const int t = (m < 4 ? 4 * sub : 64 + 4 * sub) + (m & 3);
-    oy[m] = t / 9 - 4; ox[m] = t % 9 - 4;
-  }
-  const bool two = sub < (RVO_DESC_LEN - 64) / 4;
-#pragma unroll
-  for (int r = 0; r < DESC_PER_BLOCK / 16; r++) {
-    const int idx = blockIdx.x * DESC_PER_BLOCK + r * 16 + grp;  // keypoint slot within the frame
-    if (idx >= g.kp_total) continue;
-    int lvl = 0;
-#pragma unroll
-    for (int l = 1; l < RVO_MAX_LEVELS; l++)
-      if (l < g.levels && idx >= g.lv[l].kp_off) lvl = l;
-    const LevelGeom& G = g.lv[lvl];
-    if (idx - G.kp_off >= fb.kp_cnt[slot * RVO_MAX_LEVELS + lvl]) continue;  // uniform within the 16-lane group
-    const uint8_t* __restrict__ img = level_img(fb, g, slot, lvl);
-    const size_t kidx = (size_t)slot * g.kp_total + idx;
-    const uint32_t k = fb.kp_uvs[kidx];
-    const uint8_t* c = img + (size_t)kp_y(k) * G.stride + kp_x(k);
-    int v[8];
-#pragma unroll
-    for (int m = 0; m < 4; m++) v[m] = c[oy[m] * G.stride + ox[m]];
-#pragma unroll
-    for (int m = 4; m < 8; m++) v[m] = two ? (int)c[oy[m] * G.stride + ox[m]] : 0;
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-      const int mean = sum16(v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]) / RVO_DESC_LEN;
-      const int o = 128 - mean;  // mean < 128: add and clamp at 255; mean > 128: subtract and clamp at 0
-#pragma unroll
-      for (int m = 0; m < 8; m++) v[m] = min(255, max(0, v[m] + o));
-      if (!two) { v[4] = v[5] = v[6] = v[7] = 0; }
-    }
-    uint32_t* dsc = reinterpret_cast<uint32_t*>(fb.kp_desc + kidx * RVO_DESC_LEN);
-    dsc[sub] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
-    if (two) dsc[16 + sub] = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
-  }
+  for (int l = 1; l < RVO_MAX_LEVELS; l++)
+    if (l < g.levels && idx >= g.lv[l].kp_off) lvl = l;
+  const int koff = g.lv[lvl].kp_off;
+  if (idx - koff >= fb.kp_cnt[slot * RVO_MAX_LEVELS + lvl]) return;
+  const size_t kbase = (size_t)slot * g.kp_total;
+  const size_t src = kbase + koff + fb.kp_src[kbase + idx];
+  reinterpret_cast<uint4*>(fb.kp_desc + (kbase + idx) * RVO_DESC_LEN)[piece] =
+      reinterpret_cast<const uint4*>(fb.bk_desc + src * RVO_DESC_LEN)[piece];
 }

@@ -282,6 +282,8 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   rc |= dalloc(c, &fb.kp_rect, F * g.kp_total);
   rc |= dalloc(c, &fb.kp_xyz, F * g.kp_total * 3);
   rc |= dalloc(c, &fb.kp_desc, F * g.kp_total * RVO_DESC_LEN + 64);
+  rc |= dalloc(c, &fb.bk_desc, F * g.kp_total * RVO_DESC_LEN + 64);
+  rc |= dalloc(c, &fb.kp_src, F * g.kp_total);
   rc |= dalloc(c, &fb.kp_cnt, F * RVO_MAX_LEVELS);
   rc |= dalloc(c, &fb.det_cnt, F * RVO_MAX_LEVELS);
   rc |= dalloc(c, &fb.grid_cnt, F * RVO_MAX_LEVELS);
@@ -403,7 +405,7 @@ static int enqueue_features_on(rvo_ctx* c, hipStream_t st, int n, const int32_t*
   const FrameGeom& g = c->g;
   LAUNCH_ON(c, st, "fast_grid", k_fast_grid, dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
   LAUNCH_ON(c, st, "build_keypoints", k_build_keypoints, dim3(g.levels, n), dim3(256), 0, c->fb, g, d_slots);
-  LAUNCH_ON(c, st, "descriptors", k_descriptors, dim3((g.kp_total + DESC_PER_BLOCK - 1) / DESC_PER_BLOCK, n), dim3(256), 0, c->fb, g, d_slots);
+  LAUNCH_ON(c, st, "descriptors", k_descriptors, dim3((g.kp_total * 5 + 255) / 256, n), dim3(256), 0, c->fb, g, d_slots);
   HIPCHK(hipGetLastError());
   return RVO_OK;
 }

@@ -52,6 +52,9 @@ struct FrameBufs {
   float2* kp_rect;    // [slots][kp_total] rect_base_uv (LUT values are floats, exact)
   double* kp_xyz;     // [slots][kp_total][3]
   uint8_t* kp_desc;   // [slots][kp_total][80]
+  uint8_t* bk_desc;   // [slots][total_buckets][max_per][80] descriptors of the grid-filtered keypoints, extracted by
+                      // k_fast_grid from its LDS tile; k_descriptors copies the survivors' rows into kp_desc
+  uint16_t* kp_src;   // [slots][kp_total] level-local bucket slot (bucket * max_per + j) each kept keypoint came from
   int32_t* kp_cnt;    // [slots][RVO_MAX_LEVELS]
   int32_t* det_cnt;   // [slots][RVO_MAX_LEVELS] FAST corners after NMS (adaptive threshold input)
   int32_t* grid_cnt;  // [slots][RVO_MAX_LEVELS] candidates after the grid filter
