@@ -179,3 +179,40 @@ def test_match_frames_dev_equals_two_call_path(scene, intr640):
         compare_pair(b, orc, i, rb[i], orc.match_pair(0, 1))
     a.close()
     b.close()
+
+
+def test_batches_in_flight_on_two_contexts_are_independent_and_deterministic(scene, intr640):
+    """bench.py's arrangement: two contexts take alternate batches without any synchronisation in between.  Every batch
+    must give the same bits as a context working alone, whatever is in flight beside it."""
+    import torch
+    from slam_amd.api import Context, default_params
+    n = 48
+    pairs = [synth.make_pair(500 + i, intr640, scene, invalid_frac=0.1 * (i % 2)) for i in range(4)]
+    batches = []
+    for shift in range(2):  # two different batches
+        gray = np.stack([pairs[(i + shift) % 4][j] for i in range(n) for j in (0, 2)])
+        depth = np.stack([pairs[(i + shift) % 4][j] for i in range(n) for j in (1, 3)])
+        batches.append((torch.from_numpy(gray).cuda(), torch.from_numpy(depth.view(np.int16)).cuda()))
+    torch.cuda.synchronize()
+    slots = np.arange(2 * n, dtype=np.int32)
+
+    def snapshot(ctx):
+        res = ctx.pair_results(n)
+        return [(r["status"], r["num_matches"], r["num_inliers"], r["pose"].tobytes(), r["cov"].tobytes()) for r in res]
+
+    alone = []
+    for dg, dd in batches:
+        c = Context(intr640, default_params(frame_matcher=True), max_frames=2 * n, max_pairs=n)
+        c.match_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, slots)
+        alone.append(snapshot(c))
+        c.close()
+    ctxs = [Context(intr640, default_params(frame_matcher=True), max_frames=2 * n, max_pairs=n) for _ in range(2)]
+    for c in ctxs:
+        c.set_pair_chunks(1)
+    for k in range(6):  # batches 0,1,0,1,... on contexts 0,1,0,1,... back to back
+        dg, dd = batches[k % 2]
+        ctxs[k % 2].match_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, slots)
+    for k in range(2):
+        assert snapshot(ctxs[k]) == alone[k]
+    for c in ctxs:
+        c.close()
