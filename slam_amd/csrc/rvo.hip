@@ -339,6 +339,7 @@ void rvo_destroy(rvo_ctx* c) {
     if (c->ev_pyr[i]) (void)hipEventDestroy(c->ev_pyr[i]);
     if (c->ev_rot[i]) (void)hipEventDestroy(c->ev_rot[i]);
   }
+  (void)hipGetLastError();  // leave no stale error behind for the next HIP user in the process
   delete c;
 }
 
