@@ -527,17 +527,21 @@ __device__ inline int norm_px(int v, int mean) {  // Descriptor::Normalized, fea
   return v;
 }
 
+#ifndef REFINE_GROUP
+#define REFINE_GROUP 16  // lanes per match; 8 (10 taps per lane) needs 172 VGPRs and measured 28 % slower
+#endif
 // sum over the 16 lanes of a match group (= one DPP row): xor-1 and xor-2 butterflies as quad permutes, then the
 // half-row and row mirrors; every lane ends with the total.  No LDS-crossbar shuffles on the iteration's critical path.
 __device__ inline int group16_sum(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
   v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
   v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+#if !defined(REFINE_GROUP) || REFINE_GROUP == 16
   v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
+#endif
   return v;
 }
 
-#define REFINE_GROUP 16
 #define REFINE_TAPS (RVO_DESC_LEN / REFINE_GROUP)  // 5 taps per lane
 #define REFINE_WIN_ROWS 16
 #define REFINE_WIN_PITCH 20
@@ -584,8 +588,10 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
   uint8_t* win = s_win[threadIdx.x / REFINE_GROUP];
   const int ox = kp_x(tkp) - 7, oy = kp_y(tkp) - 7;  // window = columns ox..ox+15, rows oy..oy+15
   const int xa = ox & ~3;                             // aligned column the stored rows start at
-  {
-    const int y = oy + gl;  // lane gl stages row gl
+#pragma unroll
+  for (int rr = 0; rr < REFINE_WIN_ROWS / REFINE_GROUP; rr++) {
+    const int wr = gl + REFINE_GROUP * rr;  // window row staged by this lane
+    const int y = oy + wr;
     uint32_t dw[REFINE_WIN_PITCH / 4];
 #pragma unroll
     for (int q = 0; q < REFINE_WIN_PITCH / 4; q++) {
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
       dw[q] = (y >= 0 && y < G.h && x >= 0 && x + 3 < S) ? *reinterpret_cast<const uint32_t*>(tg + y * S + x) : 0u;
     }
 #pragma unroll
-    for (int q = 0; q < REFINE_WIN_PITCH / 4; q++) reinterpret_cast<uint32_t*>(win + gl * REFINE_WIN_PITCH)[q] = dw[q];
+    for (int q = 0; q < REFINE_WIN_PITCH / 4; q++) reinterpret_cast<uint32_t*>(win + wr * REFINE_WIN_PITCH)[q] = dw[q];
   }
   wavealgo::wave_lds_sync();  // the 16 lanes of a group are in one wave
   int woff[REFINE_TAPS];
