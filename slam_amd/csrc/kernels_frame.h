@@ -105,8 +105,10 @@ __global__ __launch_bounds__(256) void k_ingest(FrameBufs fb, FrameGeom g, const
 
 // ------------------------------------------------------------------ pyramid
 #define PYR_TW 64
-#define PYR_TH 16
-#define PYR_SROWS (2 * PYR_TH + 3)   // 35
+#ifndef PYR_TH
+#define PYR_TH 32
+#endif
+#define PYR_SROWS (2 * PYR_TH + 3)   // 67
 #define PYR_SCOLS (2 * PYR_TW + 32)  // 160 bytes loaded per row as ten 16-byte words, from 2*ox0-16
 
 // One tap set of HorizontalGaussFilter (pyramid.cpp:67-99): output index r of a line of n samples.
@@ -120,7 +122,7 @@ __device__ inline int gauss_tap(F at, int n, int r) {
   return (at(o) + 4 * at(o + 1) + 7 * at(o + 2) + 4 * at(o + 3)) >> 4;
 }
 
-// grid (ceil(dw/64), ceil(dh/16), n_frames); both truncating passes fused through LDS.  Interior outputs are computed
+// grid (ceil(dw/64), ceil(dh/32), n_frames); both truncating passes fused through LDS.  Interior outputs are computed
 // four at a time on u16 pairs packed in 32-bit registers (a tap sum is at most 16*255, so plain integer adds and
 // multiplies never carry between the halves); the first/last output of a line takes the reference's edge formulas
 // through gauss_tap.
@@ -178,8 +180,8 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
   }
   __syncthreads();
   // pass 2: along y; thread = 4 adjacent outputs of one row
-  {
-    const int y = tid >> 4, x4 = (tid & 15) * 4;
+  for (int y = tid >> 4; y < PYR_TH; y += 16) {
+    const int x4 = (tid & 15) * 4;
     const int ox = ox0 + x4, oy = oy0 + y;
     if (ox < dw && oy < dh) {
       uint8_t* drow = dst + (size_t)oy * D.stride + ox;
