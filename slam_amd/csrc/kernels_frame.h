@@ -341,8 +341,46 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     const int txlo = max(3, 7 - cx0) + shl, txhi = min(sw + 2, G.w - cx0) + shl;  // fast9Detect loop bounds, feature.cpp:3042-3043
     const uint32_t b2 = (uint32_t)b | ((uint32_t)b << 16);
     unsigned long long mask = 0;
+    // Column strips: when 256 threads can take (group column, strip of <= 8 score rows) each, a thread reads the centre
+    // dwords of the 14 tile rows its strip touches once, unpacks them once, and reuses every row as the "3 up", centre
+    // and "3 down" row of three score rows (static register indexing, no index walkers).  Other shapes use the
+    // generic walker below.
+    const int nseg = 256 / ngr, rows_per = (sh + nseg - 1) / nseg;
+    const bool strips = rows_per <= 8;
+    const int seg = tid / ngr, sj = jlo + tid % ngr;
+    int r0 = 0;  // first score row of this thread's strip (strips only)
+    if (strips) {
+      const int sylo = max(0, 4 - cy0), syhi = min(sh - 1, G.h - 3 - cy0);  // rows with 3 <= gy <= h-4
+      r0 = max(seg * rows_per, sylo);
+      const int r1 = min(min(seg * rows_per + rows_per, sh) - 1, syhi);
+      const uint32_t vm = (0xFu << min(max(txlo - 4 * sj, 0), 4)) & (0xFu >> min(max(4 * sj + 3 - txhi, 0), 4)) & 0xFu;
+      if (seg < nseg && r0 <= r1 && vm) {
+        const uint32_t M = 0x00FF00FFu;
+        const uint8_t* col = s_tile + r0 * TP + 4 * sj;  // tile row r0 = "3 up" of score row r0
+        const int nrows = r1 - r0 + 1;
+        uint32_t Ce[14], Co[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+          const uint32_t C = (k < nrows + 6) ? *reinterpret_cast<const uint32_t*>(col + k * TP) : 0u;
+          Ce[k] = C & M; Co[k] = (C >> 8) & M;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          if (k < nrows) {
+            const uint8_t* row = col + (k + 3) * TP;
+            const uint32_t C = *reinterpret_cast<const uint32_t*>(row);
+            const uint32_t W = __builtin_amdgcn_alignbyte(C, *reinterpret_cast<const uint32_t*>(row - 4), 1);  // tile x-3
+            const uint32_t E = __builtin_amdgcn_alignbyte(*reinterpret_cast<const uint32_t*>(row + 4), C, 3);  // tile x+3
+            const uint32_t re = compass2(Ce[k + 3], Ce[k + 6], Ce[k], E & M, W & M, b2);
+            const uint32_t ro = compass2(Co[k + 3], Co[k + 6], Co[k], (E >> 8) & M, (W >> 8) & M, b2);
+            const uint32_t bits = ((re & 0xFFFFu) ? 1u : 0u) | ((ro & 0xFFFFu) ? 2u : 0u) | ((re >> 16) ? 4u : 0u) | ((ro >> 16) ? 8u : 0u);
+            mask |= (unsigned long long)(bits & vm) << (4 * k);
+          }
+        }
+      }
+    }
     int sy = gsy0, j = gj0;
-    for (int k = 0; sy < sh; k++) {
+    for (int k = 0; !strips && sy < sh; k++) {
       const int gy = cy0 + sy - 1;
       if (gy >= 3 && gy <= G.h - 4) {
         const uint8_t* row = s_tile + (sy + 3) * TP + 4 * j;
@@ -375,7 +413,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     const bool fits = base + wtot <= L.cand_cap;  // wave-uniform
     if (!fits && lane == 0) *s_over = 1;
     base += inc - mine;
-    sy = gsy0; j = gj0;
+    sy = strips ? r0 : gsy0; j = strips ? sj : gj0;
     for (int k = 0; fits && k < 16 && (mask >> (4 * k)); k++) {
       uint32_t bits = (uint32_t)(mask >> (4 * k)) & 0xFu;
       while (bits) {
@@ -383,8 +421,12 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
         bits &= bits - 1;
         s_cand[base++] = (uint16_t)((sy << 8) | (4 * j + i - 3 - shl));
       }
-      j += rr; sy += q;
-      if (j >= jlo + ngr) { j -= ngr; sy++; }
+      if (strips) {
+        sy++;
+      } else {
+        j += rr; sy += q;
+        if (j >= jlo + ngr) { j -= ngr; sy++; }
+      }
     }
   }
   __syncthreads();
