@@ -95,7 +95,7 @@ def main():
     import torch
     import torch.distributed as dist
     from slam_amd import synth
-    from slam_amd.api import Context, default_params
+    from slam_amd.api import PipelinedFrameMatcher
 
     # one process per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices
     dev_index = local_rank % max(1, torch.cuda.device_count())
@@ -113,18 +113,17 @@ def main():
     # latency-bound pair stages of batch k overlap the frame stages of batch k+1.  Every step is still one whole batch
     # of n_pairs pairs through ONE C-ABI call; within a context the batch then runs as a single chunk.
     n_ctx = int(os.environ.get("RVO_BENCH_CONTEXTS", "2"))
-    ctxs = [Context(intr, default_params(frame_matcher=True), max_frames=2 * n_pairs, max_pairs=n_pairs, device=dev_index)
-            for _ in range(n_ctx)]
-    if n_ctx > 1 and not os.environ.get("RVO_PAIR_CHUNKS"):
+    pipe = PipelinedFrameMatcher(intr, n_pairs, device=dev_index, depth=n_ctx)
+    ctxs = pipe.ctxs
+    if os.environ.get("RVO_PAIR_CHUNKS"):
         for c in ctxs:
-            c.set_pair_chunks(1)
-    slots = np.arange(2 * n_pairs, dtype=np.int32)
+            c.set_pair_chunks(int(os.environ["RVO_PAIR_CHUNKS"]))
     thr = ctxs[0].params.fast_init_threshold
     torch.cuda.synchronize()  # inputs are resident before anything is enqueued on the contexts' own streams
 
     def step(k):
         # FrameMatcher::Match for the whole batch: Frame::Prepare of both frames + EstimateMotion of every pair
-        ctxs[k % n_ctx].match_frames_dev(d_gray.data_ptr(), d_depth.data_ptr(), thr, slots)
+        pipe.submit(d_gray.data_ptr(), d_depth.data_ptr(), thr)
 
     def sync_all():
         for c in ctxs:
@@ -157,7 +156,7 @@ def main():
             acc["total_ms"] += v["total_ms"]
             acc["calls"] += v["calls"]
         c.profile_enable(False)
-    ctx = ctxs[(a.warmup + a.steps - 1) % n_ctx]  # holds the last batch's results
+    ctx = pipe.context_of(pipe.k - 1)  # holds the last batch's results
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -312,6 +312,45 @@ class FrameMatcher:
         return out
 
 
+class PipelinedFrameMatcher:
+    """Batches of FrameMatcher::Match (fm.cpp:32-58) kept in flight on `depth` contexts that take alternate batches
+    (double buffering): the one-workgroup-per-pair stages of one batch (clique, Gauss-Newton, initial rotation) overlap
+    the image stages of the next.  Each submit() is ONE rvo_match_frames_dev call; nothing is synchronised until
+    results() / sync().  Inputs are device pointers and are read in place (see include/rvo.h)."""
+
+    def __init__(self, intr: dict, n_pairs: int, params: Params | None = None, device: int = 0, depth: int = 2):
+        self.n_pairs = n_pairs
+        p = params or default_params(frame_matcher=True)
+        self.ctxs = [Context(intr, p, max_frames=2 * n_pairs, max_pairs=n_pairs, device=device) for _ in range(depth)]
+        if depth > 1:
+            for c in self.ctxs:
+                c.set_pair_chunks(1)
+        self.slots = np.arange(2 * n_pairs, dtype=np.int32)
+        self.k = 0
+
+    def submit(self, gray_ptr: int, depth_ptr: int, fast_thr, init_pose=None) -> int:
+        """Enqueue one batch (frames 2i, 2i+1 -> pair i).  Returns the ticket results() takes."""
+        self.ctxs[self.k % len(self.ctxs)].match_frames_dev(gray_ptr, depth_ptr, fast_thr, self.slots, init_pose)
+        self.k += 1
+        return self.k - 1
+
+    def context_of(self, ticket: int) -> Context:
+        if not (self.k - len(self.ctxs) <= ticket < self.k):
+            raise ValueError("the results of that batch have been overwritten by a later one")
+        return self.ctxs[ticket % len(self.ctxs)]
+
+    def results(self, ticket: int):
+        return self.context_of(ticket).pair_results(self.n_pairs)
+
+    def sync(self):
+        for c in self.ctxs:
+            c.sync()
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+
+
 class RGBDVOStreams:
     """N independent rgbdvo::RGBDVO instances (vo.hpp:15-102) advanced in lock-step on one GPU."""
 
