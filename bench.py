@@ -62,7 +62,8 @@ def algorithmic_bytes(geom: dict, stats: dict) -> dict:
     B["descriptors"] = nf * K * (2 + 80 + 80)
     B["init_rotation"] = npair * 2 * lv[L - 1]
     B["match"] = npair * (2 * K * 80 + 2 * K * 32 + N * 8)
-    B["refine"] = npair * N * (2 * 100 + 120)
+    B["refine"] = npair * N * (2 * 100 + 20)
+    B["refine_finish"] = npair * N * (20 + 100)
     B["consistency"] = npair * (N * N / 8 + N * 48)
     B["clique"] = npair * (N * N / 8 + N * 12)
     B["gauss_newton"] = npair * N * 88

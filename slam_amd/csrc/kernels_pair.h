@@ -558,9 +558,6 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
   const int N = off[g.levels];
   if (i_grp == 0 && gl == 0) pb.n_matches[pair] = N;
   const int rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
-  // per match of this workgroup: the refined position handed to the finishing lanes
-  __shared__ float s_tx[256 / REFINE_GROUP], s_ty[256 / REFINE_GROUP];
-  __shared__ int s_r[256 / REFINE_GROUP], s_t[256 / REFINE_GROUP];
   // 16x16 target window around the matched keypoint (rows of 5 aligned dwords): positions within +-3 px of it, i.e.
   // practically every ESM step, read their 10x10 taps from LDS instead of paying an L2 round trip per iteration
   __shared__ __align__(4) uint8_t s_win[256 / REFINE_GROUP][REFINE_WIN_ROWS * REFINE_WIN_PITCH];
@@ -691,22 +688,30 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     } else break;
     if (fabs(dxs) < 0.1 && fabs(dys) < 0.1) break;
   }
-  if (gl == 0) {
-    const int q = threadIdx.x / REFINE_GROUP;
-    s_tx[q] = tx; s_ty[q] = ty; s_r[q] = r; s_t[q] = t;
+  if (gl == 0) {  // hand the refined position to k_refine_finish
+    const size_t mi = (size_t)pair * pb.mcap + i;
+    pb.m_ref[mi] = r; pb.m_tgt[mi] = t;
+    pb.m_level[mi] = (uint8_t)lvl;
+    pb.m_uv[mi] = make_float2(tx, ty);
   }
   }
-  __syncthreads();
-  // ---- gating + refined record, motion_estimate.cpp:360-376: lanes 0..15 of the workgroup finish one match each, so
-  // the fp64 lookups below are issued by one wave instead of once per 16-lane group in all four
-  if (threadIdx.x >= 256 / REFINE_GROUP) return;
-  const int i = blockIdx.x * (256 / REFINE_GROUP) + threadIdx.x;
+}
+
+// Gating + refined record, motion_estimate.cpp:360-376: one thread per match (a kernel of its own so that its fp64
+// lookups do not add to the register budget of the ESM loop above).  grid (ceil(mcap/256), n_pairs), 256 threads.
+__global__ __launch_bounds__(256) void k_refine_finish(FrameBufs fb, FrameGeom g, PairBufs pb) {
+  const int pair = blockIdx.y + pb.pair0;
+  if (!pb.active[pair]) return;
+  const int N = pb.n_matches[pair];
+  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  int lvl = 0;
-  for (int l = 1; l < g.levels; l++) if (i >= off[l]) lvl = l;
+  const size_t mi0 = (size_t)pair * pb.mcap + i;
+  const int lvl = pb.m_level[mi0];
   const LevelGeom G = g.lv[lvl];
-  const int r = s_r[threadIdx.x], t = s_t[threadIdx.x];
-  const float tx = s_tx[threadIdx.x], ty = s_ty[threadIdx.x];
+  const int rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
+  const int r = pb.m_ref[mi0], t = pb.m_tgt[mi0];
+  const float2 txy = pb.m_uv[mi0];
+  const float tx = txy.x, ty = txy.y;
   const size_t rk = (size_t)rs * g.kp_total + G.kp_off + r, tk = (size_t)ts * g.kp_total + G.kp_off + t;
   const uint32_t tkp = fb.kp_uvs[tk];
   const float tu = (float)kp_x(tkp), tv = (float)kp_y(tkp);
