@@ -1,0 +1,107 @@
+"""configs[2] end to end: S independent RGB-D streams sharded over the ranks of one node (one process per GPU,
+slam_amd.dist.shard_range), every rank advancing its streams in lock-step with rvo_stream_step_dev on two contexts, no
+collective in the loop; at the end ONE gather of the trajectories (RCCL, gloo fallback) and rank 0 writes them in
+the pose graph's vertex file format (slam_amd/vertex_io.py) and prints one JSON line.
+
+  python tools/run_streams.py --streams 64 --frames 12
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/run_streams.py --streams 4096 --frames 300
+"""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from slam_amd import synth
+
+INTR = synth.default_intrinsics(640, 480)
+UNIQUE = 16  # distinct synthetic sequences; stream s replays sequence s % UNIQUE
+
+
+def _seq(args):
+    seed, T = args
+    return [(g, d, P) for g, d, P in synth.make_sequence(T, seed=seed, intr=INTR, scene=synth.PlaneScene(seed=seed % 8))]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=12)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from concurrent.futures import ProcessPoolExecutor
+    synth.make_texture()
+    with ProcessPoolExecutor(8) as ex:
+        seqs = list(ex.map(_seq, [(s, a.frames) for s in range(UNIQUE)]))
+
+    import torch
+    import torch.distributed as dist
+    from slam_amd.api import Context, default_params
+    from slam_amd.dist import gather_trajectories, shard_range
+    from slam_amd import vertex_io
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    if world > 1:
+        dist.init_process_group("cpu:gloo,cuda:nccl")
+    mine = shard_range(a.streams, rank, world)
+    S = len(mine)
+    dg = torch.from_numpy(np.stack([np.stack([seqs[s % UNIQUE][t][0] for s in mine]) for t in range(a.frames)])).cuda()
+    dd = torch.from_numpy(np.stack([np.stack([seqs[s % UNIQUE][t][1] for s in mine]) for t in range(a.frames)]).view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    p = default_params()
+    p.warmup_frames = 1  # the reference discards 99 frames first (vo.cpp:58-69); the synthetic sequences start at once
+    halves = [range(0, S // 2), range(S // 2, S)] if S >= 2 else [range(0, S)]
+    ctxs = []
+    for h in halves:
+        c = Context(INTR, p, max_frames=3 * len(h), max_pairs=len(h), device=dev_index)
+        c.streams_reset(len(h))
+        c.set_pair_chunks(1)
+        ctxs.append(c)
+    traj = np.zeros((S, a.frames, 14))
+    t0 = time.perf_counter()
+    for t in range(a.frames):
+        for c, h in zip(ctxs, halves):
+            c.stream_step_dev(dg[t, h.start:].data_ptr(), dd[t, h.start:].data_ptr(), len(h))
+        for c, h in zip(ctxs, halves):  # per-step poses (the only host traffic: 152 bytes per stream and frame)
+            for k, r in enumerate(c.stream_results(len(h))):
+                traj[h.start + k, t, :12] = r["pose"].reshape(12)
+                traj[h.start + k, t, 12] = r["status"]
+                traj[h.start + k, t, 13] = r["num_inliers"]
+    dt = time.perf_counter() - t0
+    # accuracy against the synthetic ground truth: pose_t maps frame t into frame 0
+    err = 0.0
+    for k, s in enumerate(mine):
+        T0 = seqs[s % UNIQUE][0][2]
+        Tn = seqs[s % UNIQUE][a.frames - 1][2]
+        gt = np.linalg.inv(T0) @ Tn
+        err = max(err, float(np.abs(traj[k, -1, :12].reshape(3, 4) - gt[:3]).max()))
+    backend = None
+    if world > 1:
+        try:
+            allt = gather_trajectories(traj, torch.device("cuda", dev_index))
+            backend = "nccl"
+        except Exception as e:
+            allt = gather_trajectories(traj, None)
+            backend = f"gloo ({type(e).__name__})"
+        stats = torch.tensor([dt, err], dtype=torch.float64)
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dt, err = float(stats[0]), float(stats[1])
+    else:
+        allt = traj
+    if rank == 0:
+        assert allt.shape == (a.streams, a.frames, 14)
+        if a.out:
+            os.makedirs(a.out, exist_ok=True)
+            for s in range(min(a.streams, 8)):
+                vertex_io.save_vertices(os.path.join(a.out, f"stream_{s:04d}.vertices"), np.arange(a.frames), allt[s, :, :12].reshape(-1, 3, 4))
+        ok = int((allt[:, 1:, 12] == 1).sum())
+        print(json.dumps(dict(streams=a.streams, frames=a.frames, n_gpus=world, stream_frames_per_s=a.streams * a.frames / dt,
+                              estimates_ok=ok, estimates=a.streams * (a.frames - 1), max_abs_pose_err_vs_truth=err,
+                              gather_backend=backend)))
+    for c in ctxs:
+        c.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
