@@ -105,6 +105,8 @@ def main():
     if world > 1:
         # gloo carries the control plane (barriers, the max-over-ranks clock); nccl (= RCCL over xGMI) carries the
         # one data collective of the path, the final trajectory gather
+        if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: do not depend on the hostname resolving
         dist.init_process_group("cpu:gloo,cuda:nccl")
     dev = torch.device("cuda", dev_index)
     d_gray = torch.from_numpy(gray).to(dev)

@@ -41,6 +41,8 @@ def main():
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     if world > 1:
+        if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("cpu:gloo,cuda:nccl")
     mine = shard_range(a.streams, rank, world)
     S = len(mine)
