@@ -106,8 +106,9 @@ def main():
         # gloo carries the control plane (barriers, the max-over-ranks clock); nccl (= RCCL over xGMI) carries the
         # one data collective of the path, the final trajectory gather
         if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: do not depend on the hostname resolving
-        dist.init_process_group("cpu:gloo,cuda:nccl")
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # RCCL bootstrap only; the data path is xGMI
+        dist.init_process_group("cpu:gloo,cuda:nccl", timeout=__import__("datetime").timedelta(seconds=180))
     dev = torch.device("cuda", dev_index)
     d_gray = torch.from_numpy(gray).to(dev)
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)

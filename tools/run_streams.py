@@ -43,7 +43,8 @@ def main():
     if world > 1:
         if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        dist.init_process_group("cpu:gloo,cuda:nccl")
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # RCCL bootstrap only; the data path is xGMI
+        dist.init_process_group("cpu:gloo,cuda:nccl", timeout=__import__("datetime").timedelta(seconds=180))
     mine = shard_range(a.streams, rank, world)
     S = len(mine)
     dg = torch.from_numpy(np.stack([np.stack([seqs[s % UNIQUE][t][0] for s in mine]) for t in range(a.frames)])).cuda()
