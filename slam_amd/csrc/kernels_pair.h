@@ -583,40 +583,40 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
   // integer position (motion_estimate.cpp:800-815), so an accepted step needs no further loads for the next one
   struct Nb { int p00, p01, p10; };
   uint8_t* win = s_win[threadIdx.x / REFINE_GROUP];
-  const int ox = kp_x(tkp) - 7, oy = kp_y(tkp) - 7;  // window = columns ox..ox+15, rows oy..oy+15
-  const int xa = ox & ~3;                             // aligned column the stored rows start at
+  int ox, oy, xa;  // window = columns ox..ox+15, rows oy..oy+15; xa = aligned column the stored rows start at
+  auto stage = [&](int cx, int cy) {  // window centred on (cx, cy); uniform per 16-lane group
+    ox = cx - 7; oy = cy - 7; xa = ox & ~3;
+    wavealgo::wave_lds_sync();  // earlier reads of the old window are done (one wave, LDS in order)
 #pragma unroll
-  for (int rr = 0; rr < REFINE_WIN_ROWS / REFINE_GROUP; rr++) {
-    const int wr = gl + REFINE_GROUP * rr;  // window row staged by this lane
-    const int y = oy + wr;
-    uint32_t dw[REFINE_WIN_PITCH / 4];
+    for (int rr = 0; rr < REFINE_WIN_ROWS / REFINE_GROUP; rr++) {
+      const int wr = gl + REFINE_GROUP * rr;  // window row staged by this lane
+      const int y = oy + wr;
+      uint32_t dw[REFINE_WIN_PITCH / 4];
 #pragma unroll
-    for (int q = 0; q < REFINE_WIN_PITCH / 4; q++) {
-      const int x = xa + 4 * q;
-      dw[q] = (y >= 0 && y < G.h && x >= 0 && x + 3 < S) ? *reinterpret_cast<const uint32_t*>(tg + y * S + x) : 0u;
+      for (int q = 0; q < REFINE_WIN_PITCH / 4; q++) {
+        const int x = xa + 4 * q;
+        dw[q] = (y >= 0 && y < G.h && x >= 0 && x + 3 < S) ? *reinterpret_cast<const uint32_t*>(tg + y * S + x) : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < REFINE_WIN_PITCH / 4; q++) reinterpret_cast<uint32_t*>(win + wr * REFINE_WIN_PITCH)[q] = dw[q];
     }
-#pragma unroll
-    for (int q = 0; q < REFINE_WIN_PITCH / 4; q++) reinterpret_cast<uint32_t*>(win + wr * REFINE_WIN_PITCH)[q] = dw[q];
-  }
-  wavealgo::wave_lds_sync();  // the 16 lanes of a group are in one wave
+    wavealgo::wave_lds_sync();  // the 16 lanes of a group are in one wave
+  };
+  stage(kp_x(tkp), kp_y(tkp));
   int woff[REFINE_TAPS];
 #pragma unroll
   for (int m = 0; m < REFINE_TAPS; m++) {
     const int t9 = gl + REFINE_GROUP * m;
     woff[m] = (t9 / 9 - 4) * REFINE_WIN_PITCH + (t9 % 9 - 4);
   }
-  // interpolated tap m at integer position (u, v) with weights w; uniform branch per 16-lane group
+  // interpolated tap m at integer position (w.u, w.v); the window must cover it (ensure_window first)
+  auto ensure_window = [&](const Wts& w) {  // a step that leaves the +-3 px the window covers re-centres it (rare)
+    if (!(w.u - 4 >= ox && w.u + 5 <= ox + 15 && w.v - 4 >= oy && w.v + 5 <= oy + 15)) stage(w.u, w.v);
+  };
   auto interp = [&](const Wts& w, int m, Nb& nb) -> int {
-    const int u = w.u, v = w.v;
-    int p11;
-    if (u - 4 >= ox && u + 5 <= ox + 15 && v - 4 >= oy && v + 5 <= oy + 15) {
-      const uint8_t* q = win + (v - oy) * REFINE_WIN_PITCH + (u - xa) + woff[m];
-      nb.p00 = q[0]; nb.p01 = q[1]; nb.p10 = q[REFINE_WIN_PITCH]; p11 = q[REFINE_WIN_PITCH + 1];
-    } else {
-      const int k = w.base + toff[m];
-      nb.p00 = tg[k]; nb.p01 = tg[k + 1]; nb.p10 = tg[k + S]; p11 = tg[k + S + 1];
-    }
-    const float f = ((w.wa * (float)nb.p00 + w.wb * (float)nb.p01) + w.wc * (float)nb.p10) + w.wd * (float)p11;
+    const uint8_t* q = win + (w.v - oy) * REFINE_WIN_PITCH + (w.u - xa) + woff[m];
+    nb.p00 = q[0]; nb.p01 = q[1]; nb.p10 = q[REFINE_WIN_PITCH];
+    const float f = ((w.wa * (float)nb.p00 + w.wb * (float)nb.p01) + w.wc * (float)nb.p10) + w.wd * (float)q[REFINE_WIN_PITCH + 1];
     return (int)f;
   };
   const int rbase = kp_y(rkp) * S + kp_x(rkp);
@@ -668,6 +668,7 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     const float ntx = (float)((double)tx + dxs), nty = (float)((double)ty + dys);
     if (!(ntx >= (float)min_xy && ntx <= (float)max_x && nty >= (float)min_xy && nty <= (float)max_y)) break;
     const Wts wn = make_wts(ntx, nty, S);
+    ensure_window(wn);
     int nraw[REFINE_TAPS];
     Nb nnb[REFINE_TAPS];
     int nsum = 0;
