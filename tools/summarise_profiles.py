@@ -1,0 +1,39 @@
+"""Copies the summaries tools/collect_profiles.sh left under gpurun_out/ into profiles/ (run here, after the gpurun call):
+python tools/summarise_profiles.py v6"""
+import collections
+import csv
+import json
+import shutil
+import sys
+
+tag = sys.argv[1]
+shutil.copy(f"gpurun_out/prof_{tag}/{tag}_kernel_stats.csv", f"profiles/r01_{tag}_kernel_stats.csv")
+line = open(f"gpurun_out/bench_{tag}.json").read().strip().splitlines()[-1]
+open(f"profiles/r01_{tag}_bench.json", "w").write(line + "\n")
+
+out = {}
+for ctr, f in (("FETCH_SIZE", "gpurun_out/pmc_fetch/f_counter_collection.csv"),
+               ("WRITE_SIZE", "gpurun_out/pmc_write/w_counter_collection.csv")):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        acc[name].append(float(r["Counter_Value"]))
+    out[ctr] = {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
+
+names = {"k_ingest": "ingest", "k_pyr_down": "pyr_down", "k_fast_grid": "fast_grid", "k_build_keypoints": "build_keypoints",
+         "k_descriptors": "descriptors", "k_init_rotation": "init_rotation", "k_match": "match", "k_refine": "refine",
+         "k_refine_finish": "refine_finish", "k_consistency": "consistency", "k_clique": "clique", "k_gn": "gauss_newton"}
+res = json.load(open("profiles/r01_pmc_traffic.json"))
+res["kernels"] = {}
+for k, n in names.items():
+    if k not in out["FETCH_SIZE"]:
+        continue
+    cnt, f = out["FETCH_SIZE"][k]
+    w = out["WRITE_SIZE"][k][1]
+    res["kernels"][n] = {"launches": cnt, "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
+                         "traffic_bytes": round((2 * f + w) * 1024)}
+json.dump(res, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+for n, v in res["kernels"].items():
+    print(n, v["launches"], v["traffic_bytes"])
+d = json.loads(line)
+print(d["value"], d["ms_per_step"], d["roofline"], d["cpu_baseline"]["value"])
