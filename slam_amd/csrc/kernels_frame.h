@@ -240,18 +240,69 @@ __device__ inline int sum16(int v) {  // 16 lanes = one DPP row: quad permutes, 
 }
 
 // compass test of phase A on two pixels held in the u16 halves of each operand: corner candidates need
-// min(max(n,s), max(e,w)) > p + b  or  max(min(n,s), min(e,w)) < p - b.  Non-zero half = pass.
+// min(max(n,s), max(e,w)) > p + b (bright) or max(min(n,s), min(e,w)) < p - b (dark).  cd2 = 0x7FFF - b in both halves;
+// bit 15 of a half of *tb / *td is the bright / dark verdict (x + 0x7FFF >= 0x8000 <=> x >= 1; all values stay in u16).
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
-__device__ inline uint32_t compass2(uint32_t p, uint32_t n, uint32_t s, uint32_t e, uint32_t w, uint32_t b2) {
+typedef short s2_t __attribute__((ext_vector_type(2)));
+__device__ inline void compass2f(uint32_t p, uint32_t n, uint32_t s, uint32_t e, uint32_t w, uint32_t cd2, uint32_t* tb, uint32_t* td) {
   const us2_t P = __builtin_bit_cast(us2_t, p), N = __builtin_bit_cast(us2_t, n), S = __builtin_bit_cast(us2_t, s);
-  const us2_t E = __builtin_bit_cast(us2_t, e), W = __builtin_bit_cast(us2_t, w), B = __builtin_bit_cast(us2_t, b2);
-  const us2_t hi = P + B;
-  const us2_t lo = __builtin_elementwise_sub_sat(P, B);
+  const us2_t E = __builtin_bit_cast(us2_t, e), W = __builtin_bit_cast(us2_t, w), CD = __builtin_bit_cast(us2_t, cd2);
   const us2_t brv = __builtin_elementwise_min(__builtin_elementwise_max(N, S), __builtin_elementwise_max(E, W));
   const us2_t dkv = __builtin_elementwise_max(__builtin_elementwise_min(N, S), __builtin_elementwise_min(E, W));
-  const us2_t r = __builtin_elementwise_sub_sat(brv, hi) | __builtin_elementwise_sub_sat(lo, dkv);
-  return __builtin_bit_cast(uint32_t, r);
+  *tb = __builtin_bit_cast(uint32_t, (us2_t)(brv + (CD - P)));
+  *td = __builtin_bit_cast(uint32_t, (us2_t)((P + CD) - dkv));
 }
+
+__device__ inline uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s2_t, a), __builtin_bit_cast(s2_t, b)));
+}
+__device__ inline uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2_t, a), __builtin_bit_cast(s2_t, b)));
+}
+__device__ inline uint32_t swap16(uint32_t a) { return __builtin_amdgcn_alignbit(a, a, 16); }
+
+// A of ONE polarity (sgn = +1: ring brighter than the centre, -1: darker) = max over the 16 nine-arcs of the arc's
+// min of sgn*(ring - p).  A corner has exactly one polarity with A > b (two nine-arcs of a 16-ring overlap), and that
+// A is fast9_A's.  Computed on i16 pairs: ring position i in the low half, i + 8 in the high half, so every sliding
+// minimum is one packed op for two positions; "position + 8" is a swap of the halves.
+__device__ inline int fast9_A_pol(const uint8_t* t, int pitch, int sgn) {
+  const int p = t[0];
+  const uint32_t r0 = t[3 * pitch], r1 = t[3 * pitch + 1], r2 = t[2 * pitch + 2], r3 = t[pitch + 3];
+  const uint32_t r4 = t[3], r5 = t[-pitch + 3], r6 = t[-2 * pitch + 2], r7 = t[-3 * pitch + 1];
+  const uint32_t r8 = t[-3 * pitch], r9 = t[-3 * pitch - 1], r10 = t[-2 * pitch - 2], r11 = t[-pitch - 3];
+  const uint32_t r12 = t[-3], r13 = t[pitch - 3], r14 = t[2 * pitch - 2], r15 = t[3 * pitch - 1];
+  const s2_t S = {(short)sgn, (short)sgn};
+  const short c1 = (short)(-p * sgn);
+  const s2_t Cc = {c1, c1};
+  auto mk = [&](uint32_t lo, uint32_t hi) {
+    const s2_t R = __builtin_bit_cast(s2_t, lo | (hi << 16));
+    return __builtin_bit_cast(uint32_t, (s2_t)(R * S + Cc));
+  };
+  const uint32_t dp[8] = {mk(r0, r8), mk(r1, r9), mk(r2, r10), mk(r3, r11), mk(r4, r12), mk(r5, r13), mk(r6, r14), mk(r7, r15)};
+  uint32_t a[8], c[8], e[8];
+#pragma unroll
+  for (int i = 0; i < 7; i++) a[i] = pk_min_i16(dp[i], dp[i + 1]);
+  a[7] = pk_min_i16(dp[7], swap16(dp[0]));
+#pragma unroll
+  for (int i = 0; i < 6; i++) c[i] = pk_min_i16(a[i], a[i + 2]);
+  c[6] = pk_min_i16(a[6], swap16(a[0]));
+  c[7] = pk_min_i16(a[7], swap16(a[1]));
+#pragma unroll
+  for (int i = 0; i < 4; i++) e[i] = pk_min_i16(c[i], c[i + 4]);
+#pragma unroll
+  for (int i = 4; i < 8; i++) e[i] = pk_min_i16(c[i], swap16(c[i - 4]));
+  uint32_t best = pk_min_i16(e[0], swap16(dp[0]));
+#pragma unroll
+  for (int i = 1; i < 8; i++) best = pk_max_i16(best, pk_min_i16(e[i], swap16(dp[i])));
+  return max((int)(short)(best & 0xFFFFu), (int)best >> 16);
+}
+
+#ifdef RVO_PHASE_TIMING  // ablation builds only (never the product library; tools/exp_phases.py): stop after a phase
+__device__ int g_fast_stop;  // ablation: return after phase i (99 = run everything)
+#define FAST_PHASE(i) do { if (g_fast_stop_k == i) return; } while (0)
+#else
+#define FAST_PHASE(i) do { } while (0)
+#endif
 
 struct FastLds {  // byte offsets into dynamic LDS, computed on the host (all multiples of 4)
   int tile_pitch, score_pitch;
@@ -277,6 +328,9 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   const int tid = threadIdx.x;
   const int slot = slots[blockIdx.y];
   if (slot < 0) return;
+#ifdef RVO_PHASE_TIMING
+  const int g_fast_stop_k = *(volatile int*)&g_fast_stop;
+#endif
   const int b = thr[blockIdx.y];
   int lvl = 0;
   const int gb = blockIdx.x;  // bucket index within the slot
@@ -322,61 +376,72 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   // (independent LDS reads, no per-iteration atomics), then each wave reserves queue space with ONE atomicAdd.
   const int sw = cw + 2, sh = ch + 2;
   uint16_t* s_cand = reinterpret_cast<uint16_t*>(s_list);  // aliases the survivor list (used after later barriers)
-  int* s_ncand = s_misc + 8;
-  int* s_over = s_misc + 9;  // the candidate queue (L.cand_cap entries, half of the pixels) overflowed: dense fallback
+  int* s_ncand = s_misc + 8;  // [0] bright entries (from the front), [1] dark entries (from the back)
+  int* s_over = s_misc + 10;  // the candidate queue (L.cand_cap entries, half of the pixels) overflowed: dense fallback
   uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_misc + 16);  // NMS survivor bitmap, one bit per cell pixel (raster)
   const int P = cw * ch;
   const int nwords = (P + 31) >> 5;
-  if (tid == 0) { *s_ncand = 0; *s_over = 0; }
+  if (tid == 0) { s_ncand[0] = 0; s_ncand[1] = 0; *s_over = 0; }
   for (int w = tid; w < nwords; w += 256) s_bits[w] = 0;
   for (int w = tid; w < (L.off_list - L.off_score) / 4; w += 256) reinterpret_cast<uint32_t*>(s_score)[w] = 0;
   __syncthreads();
+  FAST_PHASE(0);  // staging
   const int lane = tid & 63;
+  const int qcap = L.cand_cap;
   {
-    // 4 horizontally adjacent pixels per iteration: 5 aligned LDS dwords (centre, left, right, 3 rows up, 3 rows down)
+    // 4 horizontally adjacent pixels per iteration: aligned LDS dwords (centre, left, right, 3 rows up, 3 rows down)
     // feed two packed-u16 evaluations (even / odd bytes).  Group j of score row sy covers tile x = 4j..4j+3.
     const int jlo = (shl + 3) >> 2, ngr = ((shl + sw + 2) >> 2) - jlo + 1;  // score column sx sits at tile x = sx + 3 + shl
     const int q = 256 / ngr, rr = 256 % ngr;
     const int gsy0 = tid / ngr, gj0 = jlo + tid % ngr;
     const int txlo = max(3, 7 - cx0) + shl, txhi = min(sw + 2, G.w - cx0) + shl;  // fast9Detect loop bounds, feature.cpp:3042-3043
-    const uint32_t b2 = (uint32_t)b | ((uint32_t)b << 16);
-    unsigned long long mask = 0;
+    const uint32_t cd1 = 0x7FFFu - (uint32_t)min(b, 255);
+    const uint32_t cd2 = cd1 | (cd1 << 16);
     // Column strips: when 256 threads can take (group column, strip of <= 8 score rows) each, a thread reads the centre
     // dwords of the 14 tile rows its strip touches once, unpacks them once, and reuses every row as the "3 up", centre
-    // and "3 down" row of three score rows (static register indexing, no index walkers).  Other shapes use the
-    // generic walker below.
+    // and "3 down" row of three score rows (static register indexing, no index walkers).  The verdicts of a strip are
+    // shifted into two 32-bit masks (bright, dark): row k's pixels 0,1 at bits 2k+1, 2k and pixels 2,3 at 17+2k, 16+2k.
+    // Other shapes use the generic walker below (64-bit masks, 4 bits per visited group).
     const int nseg = 256 / ngr, rows_per = (sh + nseg - 1) / nseg;
     const bool strips = rows_per <= 8;
     const int seg = tid / ngr, sj = jlo + tid % ngr;
     int r0 = 0;  // first score row of this thread's strip (strips only)
+    uint32_t sb = 0, sdk = 0;             // strips: bright / dark masks
+    unsigned long long gb64 = 0, gd64 = 0;  // generic walker: bright / dark masks
     if (strips) {
       const int sylo = max(0, 4 - cy0), syhi = min(sh - 1, G.h - 3 - cy0);  // rows with 3 <= gy <= h-4
       r0 = max(seg * rows_per, sylo);
       const int r1 = min(min(seg * rows_per + rows_per, sh) - 1, syhi);
       const uint32_t vm = (0xFu << min(max(txlo - 4 * sj, 0), 4)) & (0xFu >> min(max(4 * sj + 3 - txhi, 0), 4)) & 0xFu;
       if (seg < nseg && r0 <= r1 && vm) {
-        const uint32_t M = 0x00FF00FFu;
         const uint8_t* col = s_tile + r0 * TP + 4 * sj;  // tile row r0 = "3 up" of score row r0
         const int nrows = r1 - r0 + 1;
         uint32_t Ce[14], Co[14];
 #pragma unroll
         for (int k = 0; k < 14; k++) {
           const uint32_t C = (k < nrows + 6) ? *reinterpret_cast<const uint32_t*>(col + k * TP) : 0u;
-          Ce[k] = C & M; Co[k] = (C >> 8) & M;
+          Ce[k] = C & 0x00FF00FFu;
+          Co[k] = __builtin_amdgcn_perm(0u, C, 0x0C030C01u);
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          if (k < nrows) {
-            const uint8_t* row = col + (k + 3) * TP;
-            const uint32_t C = *reinterpret_cast<const uint32_t*>(row);
-            const uint32_t W = __builtin_amdgcn_alignbyte(C, *reinterpret_cast<const uint32_t*>(row - 4), 1);  // tile x-3
-            const uint32_t E = __builtin_amdgcn_alignbyte(*reinterpret_cast<const uint32_t*>(row + 4), C, 3);  // tile x+3
-            const uint32_t re = compass2(Ce[k + 3], Ce[k + 6], Ce[k], E & M, W & M, b2);
-            const uint32_t ro = compass2(Co[k + 3], Co[k + 6], Co[k], (E >> 8) & M, (W >> 8) & M, b2);
-            const uint32_t bits = ((re & 0xFFFFu) ? 1u : 0u) | ((ro & 0xFFFFu) ? 2u : 0u) | ((re >> 16) ? 4u : 0u) | ((ro >> 16) ? 8u : 0u);
-            mask |= (unsigned long long)(bits & vm) << (4 * k);
-          }
+        for (int k = 0; k < 8; k++) {  // rows past the strip read other LDS rows of this workgroup and are masked off below
+          const uint8_t* row = col + (k + 3) * TP;
+          const uint32_t C = *reinterpret_cast<const uint32_t*>(row);
+          const uint32_t Lw = *reinterpret_cast<const uint32_t*>(row - 4);
+          const uint32_t R = *reinterpret_cast<const uint32_t*>(row + 4);
+          // west = tile x-3 of the four pixels = Lw.b1 Lw.b2 Lw.b3 C.b0; east = x+3 = C.b3 R.b0 R.b1 R.b2
+          const uint32_t We = __builtin_amdgcn_perm(0u, Lw, 0x0C030C01u), Wo = __builtin_amdgcn_perm(C, Lw, 0x0C040C02u);
+          const uint32_t Ee = __builtin_amdgcn_perm(R, C, 0x0C050C03u), Eo = __builtin_amdgcn_perm(R, 0u, 0x0C060C04u);
+          uint32_t tbe, tde, tbo, tdo;
+          compass2f(Ce[k + 3], Ce[k + 6], Ce[k], Ee, We, cd2, &tbe, &tde);
+          compass2f(Co[k + 3], Co[k + 6], Co[k], Eo, Wo, cd2, &tbo, &tdo);
+          sb = (sb >> 2) | (tbe & 0x80008000u) | ((tbo >> 1) & 0x40004000u);
+          sdk = (sdk >> 2) | (tde & 0x80008000u) | ((tdo >> 1) & 0x40004000u);
         }
+        const uint32_t keep = (((1u << (2 * nrows)) - 1u) * 0x00010001u) &
+                              (((vm & 1u) ? 0x0000AAAAu : 0u) | ((vm & 2u) ? 0x00005555u : 0u) | ((vm & 4u) ? 0xAAAA0000u : 0u) |
+                               ((vm & 8u) ? 0x55550000u : 0u));
+        sb &= keep; sdk &= keep;
       }
     }
     int sy = gsy0, j = gj0;
@@ -392,54 +457,81 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
         const uint32_t W = __builtin_amdgcn_alignbyte(C, Lw, 1);  // tile x-3 of the four pixels
         const uint32_t E = __builtin_amdgcn_alignbyte(R, C, 3);   // tile x+3
         const uint32_t M = 0x00FF00FFu;
-        const uint32_t re = compass2(C & M, D & M, U & M, E & M, W & M, b2);
-        const uint32_t ro = compass2((C >> 8) & M, (D >> 8) & M, (U >> 8) & M, (E >> 8) & M, (W >> 8) & M, b2);
-        const uint32_t bits = ((re & 0xFFFFu) ? 1u : 0u) | ((ro & 0xFFFFu) ? 2u : 0u) | ((re >> 16) ? 4u : 0u) | ((ro >> 16) ? 8u : 0u);
-        const uint32_t vm = (0xFu << min(max(txlo - 4 * j, 0), 4)) & (0xFu >> min(max(4 * j + 3 - txhi, 0), 4));
-        mask |= (unsigned long long)(bits & vm & 0xFu) << (4 * k);
+        uint32_t tbe, tde, tbo, tdo;
+        compass2f(C & M, D & M, U & M, E & M, W & M, cd2, &tbe, &tde);
+        compass2f((C >> 8) & M, (D >> 8) & M, (U >> 8) & M, (E >> 8) & M, (W >> 8) & M, cd2, &tbo, &tdo);
+        const uint32_t vm = (0xFu << min(max(txlo - 4 * j, 0), 4)) & (0xFu >> min(max(4 * j + 3 - txhi, 0), 4)) & 0xFu;
+        const uint32_t bb = ((tbe >> 15) & 1u) | ((tbo >> 14) & 2u) | ((tbe >> 29) & 4u) | ((tbo >> 28) & 8u);
+        const uint32_t bd = ((tde >> 15) & 1u) | ((tdo >> 14) & 2u) | ((tde >> 29) & 4u) | ((tdo >> 28) & 8u);
+        gb64 |= (unsigned long long)(bb & vm) << (4 * k);
+        gd64 |= (unsigned long long)(bd & vm) << (4 * k);
       }
       j += rr; sy += q;
       if (j >= jlo + ngr) { j -= ngr; sy++; }
     }
-    // wave-level reservation
-    const int mine = __popcll(mask);
+    // wave-level reservation: bright candidates fill the queue from the front, dark ones from the back (a pixel that
+    // passes both tests is queued twice), so phase B evaluates ONE polarity per entry.
+    const int mineb = strips ? __popc(sb) : __popcll(gb64), mined = strips ? __popc(sdk) : __popcll(gd64);
+    const int mine = mineb | (mined << 16);
     int inc = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
     const int wtot = __shfl(inc, 63, 64);
-    int base = 0;
-    if (lane == 0 && wtot) base = atomicAdd(s_ncand, wtot);
-    base = __shfl(base, 0, 64);
-    const bool fits = base + wtot <= L.cand_cap;  // wave-uniform
+    const int wb = wtot & 0xFFFF, wd = wtot >> 16;
+    int baseb = 0, based = 0;
+    if (lane == 0 && wb) baseb = atomicAdd(s_ncand, wb);
+    if (lane == 0 && wd) based = atomicAdd(s_ncand + 1, wd);
+    baseb = __shfl(baseb, 0, 64);
+    based = __shfl(based, 0, 64);
+    const bool fits = baseb + wb <= qcap && based + wd <= qcap;  // wave-uniform; the two ends meeting is checked after the barrier
     if (!fits && lane == 0) *s_over = 1;
-    base += inc - mine;
-    sy = strips ? r0 : gsy0; j = strips ? sj : gj0;
-    for (int k = 0; fits && k < 16 && (mask >> (4 * k)); k++) {
-      uint32_t bits = (uint32_t)(mask >> (4 * k)) & 0xFu;
-      while (bits) {
-        const int i = __ffs(bits) - 1;
-        bits &= bits - 1;
-        s_cand[base++] = (uint16_t)((sy << 8) | (4 * j + i - 3 - shl));
-      }
-      if (strips) {
-        sy++;
-      } else {
+    int posb = baseb + ((inc - mine) & 0xFFFF);
+    int posd = qcap - 1 - (based + ((inc - mine) >> 16));
+    if (fits && strips) {
+      auto drain = [&](uint32_t m, int& pos, int step) {
+        while (m) {
+          const int qb = __ffs(m) - 1;
+          m &= m - 1;
+          const int k = (qb & 15) >> 1, i = 1 - (qb & 1) + 2 * (qb >> 4);
+          s_cand[pos] = (uint16_t)(((r0 + k) << 8) | (4 * sj + i - 3 - shl));
+          pos += step;
+        }
+      };
+      drain(sb, posb, 1);
+      drain(sdk, posd, -1);
+    }
+    if (fits && !strips) {
+      sy = gsy0; j = gj0;
+      for (int k = 0; k < 16 && ((gb64 | gd64) >> (4 * k)); k++) {
+        uint32_t bits = (uint32_t)(gb64 >> (4 * k)) & 0xFu;
+        while (bits) {
+          const int i = __ffs(bits) - 1;
+          bits &= bits - 1;
+          s_cand[posb++] = (uint16_t)((sy << 8) | (4 * j + i - 3 - shl));
+        }
+        bits = (uint32_t)(gd64 >> (4 * k)) & 0xFu;
+        while (bits) {
+          const int i = __ffs(bits) - 1;
+          bits &= bits - 1;
+          s_cand[posd--] = (uint16_t)((sy << 8) | (4 * j + i - 3 - shl));
+        }
         j += rr; sy += q;
         if (j >= jlo + ngr) { j -= ngr; sy++; }
       }
     }
   }
   __syncthreads();
-  // ---- phase B: score A = fast9CornerScore + 1 for every queued pixel; it is a corner iff A > b (the segment
-  // test passes at threshold b iff b < A).  All lanes busy; measured faster than a separate detect pass.
-  const bool over = *s_over != 0;
-  const int ncand = over ? 0 : *s_ncand;
+  FAST_PHASE(1);  // phase A
+  // ---- phase B: score A = fast9CornerScore + 1 of the queued polarity for every queue entry; the pixel is a corner iff
+  // A > b (the segment test passes at threshold b iff b < A).  Entry c < nb: bright, entry qcap-1-(c-nb): dark.
+  const int nb = s_ncand[0], nd = s_ncand[1];
+  const bool over = *s_over != 0 || nb + nd > qcap;
+  const int ncand = over ? 0 : nb + nd;
   for (int c = tid; c < ncand; c += 256) {
-    const uint16_t v = s_cand[c];
+    const bool bright = c < nb;
+    const uint16_t v = s_cand[bright ? c : qcap - 1 - (c - nb)];
     const int sy = v >> 8, sx = v & 255;
-    int d[16];
-    fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3 + shl), TP, d);
-    const int A = fast9_A(d);
+    const int A = fast9_A_pol(s_tile + (sy + 3) * TP + (sx + 3 + shl), TP, bright ? 1 : -1);
     if (A > b) s_score[sy * SP + sx] = (uint8_t)A;
   }
   if (over) {  // more than half of the pixels passed the compass test (dense noise): score every pixel
@@ -454,6 +546,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     }
   }
   __syncthreads();
+  FAST_PHASE(2);  // phase B
 
   // ---- NMS (feature.cpp:5960-6056: a corner survives iff no 8-neighbour corner has score >= its own) on the
   // queued pixels only (all cell pixels in the dense fallback); survivors set one bit of a raster-ordered bitmap.
@@ -469,7 +562,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     }
   };
   for (int c = tid; c < ncand; c += 256) {
-    const uint16_t v = s_cand[c];
+    const uint16_t v = s_cand[c < nb ? c : qcap - 1 - (c - nb)];
     const int sy = v >> 8, sx = v & 255;
     if (sx < 1 || sx > cw || sy < 1 || sy > ch) continue;  // halo pixels belong to neighbouring buckets
     nms(sy, sx);
@@ -477,6 +570,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   if (over)
     for (int i = tid; i < P; i += 256) nms(i / cw + 1, i % cw + 1);
   __syncthreads();
+  FAST_PHASE(3);  // NMS
   // ---- raster-ordered compaction of the bitmap (the order the reference pushes keypoints into the bucket)
   int total = 0, base_run = 0;
   for (int w0 = 0; w0 < nwords; w0 += 256) {
@@ -496,6 +590,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   }
   total = base_run;
   __syncthreads();
+  FAST_PHASE(4);  // compaction
 
   // ---- GridKeyPointFilter::Filter for this bucket (pyramid.cpp:38-50)
   const int n = min(total, L.list_cap);
@@ -505,6 +600,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     wavealgo::wave_nth_element<22>(s_list, maxp, n, li, li + L.list_cap);
   }
   __syncthreads();
+  FAST_PHASE(5);  // nth_element
   const int keep = min(n, maxp);
   const size_t bslot = ((size_t)slot * g.total_buckets + gb) * maxp;
   uint32_t* out = fb.bk_kp + bslot;
@@ -541,6 +637,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
       if (two) dsc[16 + sub] = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
     }
   }
+  FAST_PHASE(6);  // lists + descriptors (thread 0's share)
 }
 
 // ------------------------------------------------------------------ keypoint records + XYZ
