@@ -16,16 +16,23 @@ __device__ inline int wave_sum(int v) {
   return v;
 }
 
+// inclusive scan over the 64 lanes of a wave (all lanes active) on the DPP network: Hillis-Steele inside each row of 16
+// (row_shr 1,2,4,8), then the row totals are carried with row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3).
+__device__ inline int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+  return v;
+}
+
 // exclusive scan of one int per thread over a 256-thread block; *total = block sum.
 // s_wave must hold 4 ints.  Contains two barriers.
 __device__ inline int block_excl_scan_256(int v, int* s_wave, int* total) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int n = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += n;
-  }
+  const int inc = wave_incl_scan(v);
   __syncthreads();  // protect s_wave from the previous call's readers
   if (lane == 63) s_wave[wid] = inc;
   __syncthreads();
@@ -44,12 +51,7 @@ __device__ inline int block_excl_scan_256(int v, int* s_wave, int* total) {
 template <int NW>
 __device__ inline int block_excl_scan(int v, int* s_wave, int* total) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int n = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += n;
-  }
+  const int inc = wave_incl_scan(v);
   __syncthreads();
   if (lane == 63) s_wave[wid] = inc;
   __syncthreads();
@@ -326,14 +328,25 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   int* s_misc = reinterpret_cast<int*>(lds + L.off_misc);  // [0..3] wave sums
 
   const int tid = threadIdx.x;
-  const int slot = slots[blockIdx.y];
+  // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), so the natural
+  // mapping would put the buckets of one frame, whose tiles share halo lines, behind 8 different L2s.  Within every
+  // group of 8 frames the linear ids are re-dealt so that all buckets of a frame are congruent mod 8.
+  int gb = blockIdx.x, fi = blockIdx.y;  // bucket index within the slot, frame of the batch
+  {
+    const int nbk = gridDim.x, lin = blockIdx.y * nbk + blockIdx.x, grp = lin / (8 * nbk);
+    if (grp * 8 + 8 <= (int)gridDim.y) {
+      const int r = lin - grp * 8 * nbk;
+      fi = grp * 8 + (r & 7);
+      gb = r >> 3;
+    }
+  }
+  const int slot = slots[fi];
   if (slot < 0) return;
 #ifdef RVO_PHASE_TIMING
   const int g_fast_stop_k = *(volatile int*)&g_fast_stop;
 #endif
-  const int b = thr[blockIdx.y];
+  const int b = thr[fi];
   int lvl = 0;
-  const int gb = blockIdx.x;  // bucket index within the slot
 #pragma unroll
   for (int l = 1; l < RVO_MAX_LEVELS; l++)
     if (l < g.levels && gb >= g.lv[l].bucket_off) lvl = l;
@@ -473,16 +486,14 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     // passes both tests is queued twice), so phase B evaluates ONE polarity per entry.
     const int mineb = strips ? __popc(sb) : __popcll(gb64), mined = strips ? __popc(sdk) : __popcll(gd64);
     const int mine = mineb | (mined << 16);
-    int inc = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
-    const int wtot = __shfl(inc, 63, 64);
+    const int inc = wave_incl_scan(mine);
+    const int wtot = __builtin_amdgcn_readlane(inc, 63);
     const int wb = wtot & 0xFFFF, wd = wtot >> 16;
     int baseb = 0, based = 0;
     if (lane == 0 && wb) baseb = atomicAdd(s_ncand, wb);
     if (lane == 0 && wd) based = atomicAdd(s_ncand + 1, wd);
-    baseb = __shfl(baseb, 0, 64);
-    based = __shfl(based, 0, 64);
+    baseb = __builtin_amdgcn_readfirstlane(baseb);
+    based = __builtin_amdgcn_readfirstlane(based);
     const bool fits = baseb + wb <= qcap && based + wd <= qcap;  // wave-uniform; the two ends meeting is checked after the barrier
     if (!fits && lane == 0) *s_over = 1;
     int posb = baseb + ((inc - mine) & 0xFFFF);
