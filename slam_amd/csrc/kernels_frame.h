@@ -130,12 +130,15 @@ __device__ inline int gauss_tap(F at, int n, int r) {
 // through gauss_tap.
 __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots, int lvl) {
   const LevelGeom S = g.lv[lvl - 1], D = g.lv[lvl];
-  const int slot = slots[blockIdx.z];
+  int tile, fi;  // XCD-aware: the tiles of a frame share source lines
+  xcd_map(gridDim.x * gridDim.y, gridDim.z, blockIdx.y * gridDim.x + blockIdx.x, blockIdx.z, &tile, &fi);
+  const int tile_y = tile / (int)gridDim.x, tile_x = tile - tile_y * (int)gridDim.x;
+  const int slot = slots[fi];
   if (slot < 0) return;  // stream still in warm-up (vo.cpp:58-69)
   const uint8_t* __restrict__ src = level_img(fb, g, slot, lvl - 1);
   uint8_t* __restrict__ dst = fb.img + (size_t)slot * g.img_bytes + D.img_off;
   const int dw = S.w / 2, dh = S.h / 2;
-  const int ox0 = blockIdx.x * PYR_TW, oy0 = blockIdx.y * PYR_TH;
+  const int ox0 = tile_x * PYR_TW, oy0 = tile_y * PYR_TH;
   const int sx0 = 2 * ox0 - 16, sy0 = 2 * oy0 - 2;
   __shared__ __align__(16) uint8_t s_src[PYR_SROWS][PYR_SCOLS];
   __shared__ __align__(16) uint16_t s_mid[PYR_SROWS][PYR_TW];
@@ -328,18 +331,8 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   int* s_misc = reinterpret_cast<int*>(lds + L.off_misc);  // [0..3] wave sums
 
   const int tid = threadIdx.x;
-  // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), so the natural
-  // mapping would put the buckets of one frame, whose tiles share halo lines, behind 8 different L2s.  Within every
-  // group of 8 frames the linear ids are re-dealt so that all buckets of a frame are congruent mod 8.
-  int gb = blockIdx.x, fi = blockIdx.y;  // bucket index within the slot, frame of the batch
-  {
-    const int nbk = gridDim.x, lin = blockIdx.y * nbk + blockIdx.x, grp = lin / (8 * nbk);
-    if (grp * 8 + 8 <= (int)gridDim.y) {
-      const int r = lin - grp * 8 * nbk;
-      fi = grp * 8 + (r & 7);
-      gb = r >> 3;
-    }
-  }
+  int gb, fi;  // bucket index within the slot, frame of the batch (XCD-aware: a frame's tiles share halo lines)
+  xcd_map(gridDim.x, gridDim.y, blockIdx.x, blockIdx.y, &gb, &fi);
   const int slot = slots[fi];
   if (slot < 0) return;
 #ifdef RVO_PHASE_TIMING
@@ -401,10 +394,15 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   FAST_PHASE(0);  // staging
   const int lane = tid & 63;
   const int qcap = L.cand_cap;
+  // four-pixel groups: group j of score row sy covers tile x = 4j..4j+3 (score column sx sits at tile x = sx + 3 + shl)
+  const int jlo = (shl + 3) >> 2, ngr = ((shl + sw + 2) >> 2) - jlo + 1;
+  const int nseg = 256 / ngr, rows_per = (sh + nseg - 1) / nseg;
+  const bool strips = rows_per <= 8;      // column strips (below); otherwise the generic walker
+  const int sylo = max(0, 4 - cy0);       // first score row with gy >= 3
+  const int inv_ngr = (65536 + ngr - 1) / ngr;  // t / ngr == (t * inv_ngr) >> 16 for t < 256
   {
     // 4 horizontally adjacent pixels per iteration: aligned LDS dwords (centre, left, right, 3 rows up, 3 rows down)
     // feed two packed-u16 evaluations (even / odd bytes).  Group j of score row sy covers tile x = 4j..4j+3.
-    const int jlo = (shl + 3) >> 2, ngr = ((shl + sw + 2) >> 2) - jlo + 1;  // score column sx sits at tile x = sx + 3 + shl
     const int q = 256 / ngr, rr = 256 % ngr;
     const int gsy0 = tid / ngr, gj0 = jlo + tid % ngr;
     const int txlo = max(3, 7 - cx0) + shl, txhi = min(sw + 2, G.w - cx0) + shl;  // fast9Detect loop bounds, feature.cpp:3042-3043
@@ -415,14 +413,12 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     // and "3 down" row of three score rows (static register indexing, no index walkers).  The verdicts of a strip are
     // shifted into two 32-bit masks (bright, dark): row k's pixels 0,1 at bits 2k+1, 2k and pixels 2,3 at 17+2k, 16+2k.
     // Other shapes use the generic walker below (64-bit masks, 4 bits per visited group).
-    const int nseg = 256 / ngr, rows_per = (sh + nseg - 1) / nseg;
-    const bool strips = rows_per <= 8;
     const int seg = tid / ngr, sj = jlo + tid % ngr;
     int r0 = 0;  // first score row of this thread's strip (strips only)
     uint32_t sb = 0, sdk = 0;             // strips: bright / dark masks
     unsigned long long gb64 = 0, gd64 = 0;  // generic walker: bright / dark masks
     if (strips) {
-      const int sylo = max(0, 4 - cy0), syhi = min(sh - 1, G.h - 3 - cy0);  // rows with 3 <= gy <= h-4
+      const int syhi = min(sh - 1, G.h - 3 - cy0);  // rows sylo..syhi have 3 <= gy <= h-4
       r0 = max(seg * rows_per, sylo);
       const int r1 = min(min(seg * rows_per + rows_per, sh) - 1, syhi);
       const uint32_t vm = (0xFu << min(max(txlo - 4 * sj, 0), 4)) & (0xFu >> min(max(4 * sj + 3 - txhi, 0), 4)) & 0xFu;
@@ -499,12 +495,13 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     int posb = baseb + ((inc - mine) & 0xFFFF);
     int posd = qcap - 1 - (based + ((inc - mine) >> 16));
     if (fits && strips) {
+      // the loop runs as long as the fullest lane of the wave, so an entry is just (thread << 5 | mask bit); phase B,
+      // where every lane has one entry, turns it into (sy << 8 | sx)
       auto drain = [&](uint32_t m, int& pos, int step) {
         while (m) {
           const int qb = __ffs(m) - 1;
           m &= m - 1;
-          const int k = (qb & 15) >> 1, i = 1 - (qb & 1) + 2 * (qb >> 4);
-          s_cand[pos] = (uint16_t)(((r0 + k) << 8) | (4 * sj + i - 3 - shl));
+          s_cand[pos] = (uint16_t)((tid << 5) | qb);
           pos += step;
         }
       };
@@ -540,8 +537,16 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   const int ncand = over ? 0 : nb + nd;
   for (int c = tid; c < ncand; c += 256) {
     const bool bright = c < nb;
-    const uint16_t v = s_cand[bright ? c : qcap - 1 - (c - nb)];
-    const int sy = v >> 8, sx = v & 255;
+    const int qi = bright ? c : qcap - 1 - (c - nb);
+    const int v = s_cand[qi];
+    int sy = v >> 8, sx = v & 255;
+    if (strips) {  // entry = (producer thread << 5 | bit of its strip mask): row k's pixels 0,1 at bits 2k+1, 2k, pixels 2,3 at 17+2k, 16+2k
+      const int t = v >> 5, qb = v & 31;
+      const int seg = (t * inv_ngr) >> 16;
+      sy = max(seg * rows_per, sylo) + ((qb & 15) >> 1);
+      sx = 4 * (jlo + t - seg * ngr) + 1 - (qb & 1) + 2 * (qb >> 4) - 3 - shl;
+      s_cand[qi] = (uint16_t)((sy << 8) | sx);  // for the NMS pass (same thread, same entry)
+    }
     const int A = fast9_A_pol(s_tile + (sy + 3) * TP + (sx + 3 + shl), TP, bright ? 1 : -1);
     if (A > b) s_score[sy * SP + sx] = (uint8_t)A;
   }

@@ -781,11 +781,11 @@ __global__ __launch_bounds__(256) void k_refine_finish(FrameBufs fb, FrameGeom g
 }
 
 // ------------------------------------------------------------------ consistency matrix
-#define CONS_TILE 1024
-// grid (ceil(mcap/256), n_pairs), 256 threads: lane = row i of row tile I = blockIdx.x; columns are staged through
-// LDS in tiles of 1024 matches as fp32 (broadcast reads).  The matrix is symmetric, so a row tile only evaluates the
-// columns j >= 256*I: its own 256 columns directly, and for the columns of later tiles every computed 32-bit word is
-// also transposed with ballots and stored into the rows of those columns (their words < 8*(I+1) come from here).
+#define CONS_TILE 256
+// grid (T(T+1)/2, n_pairs), T = ceil(mcap/256), 256 threads: one workgroup per 256x256 tile (I, J >= I) of the upper
+// triangle; thread = row i of row tile I, the 256 columns of tile J are staged in LDS as fp32 (broadcast reads).  The
+// matrix is symmetric: for J > I every computed 32-bit word is also transposed with ballots and stored into the rows
+// of tile J (their words for columns of tile I come from here).
 //
 // The test |‖ref_j-ref_i‖ - ‖tgt_j-tgt_i‖| < thr (motion_estimate.cpp:505-507) is first decided without square
 // roots in fp32: with a, b the squared distances, |sqrt a - sqrt b| < t  <=>  a+b < t^2  or  (a-b)^2 < t^2 (2(a+b) - t^2).
@@ -797,11 +797,17 @@ typedef float f2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) {
   __shared__ float s_c[(CONS_TILE + 32) * 6];
   const int pair = blockIdx.y + pb.pair0;
-  for (int k = threadIdx.x; k < (CONS_TILE + 32) * 6; k += 256) s_c[k] = 0.f;  // padding columns stay finite
   if (!pb.active[pair]) return;
   const int N = pb.n_matches[pair];
-  const int jstart = blockIdx.x * 256;
-  if (jstart >= N) return;
+  // blockIdx.x enumerates the tile pairs (I, J >= I) of the upper triangle, row tile by row tile: equal work per workgroup
+  // and several times more workgroups than CUs (one workgroup per row tile left the CUs with uneven column counts)
+  const int T = (pb.mcap + 255) / 256;
+  int tj = blockIdx.x, ti = 0;
+  while (tj >= T - ti) { tj -= T - ti; ti++; }
+  tj += ti;
+  const int jstart = ti * 256, jcol = tj * 256;
+  if (jcol >= N) return;  // (jstart <= jcol)
+  for (int k = threadIdx.x; k < (CONS_TILE + 32) * 6; k += 256) s_c[k] = 0.f;  // padding columns stay finite
   const int lane = threadIdx.x & 63;
   const int i = jstart + threadIdx.x;
   const int iw0 = jstart + (threadIdx.x & ~63);  // first row of this wave
@@ -817,7 +823,8 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
   const float tlo2 = tlo * tlo, thi2 = thi * thi;
   const float lo_m = 2.f * tlo2, lo_c = -tlo2 * tlo2, hi_m = 2.f * thi2, hi_c = -thi2 * thi2;  // rhs = fma(m, a+b, c)
   uint32_t* row = pb.cbits + (mb + ii) * pb.cwords;
-  for (int j0 = jstart; j0 < N; j0 += CONS_TILE) {
+  {
+    const int j0 = jcol;
     const int nt = min(CONS_TILE, N - j0);
     __syncthreads();
     // LDS layout: per pair of columns (2p, 2p+1) twelve floats  rx0 rx1 ry0 ry1 rz0 rz1 tx0 tx1 ty0 ty1 tz0 tz1,
@@ -829,7 +836,7 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
       d[6] = (float)pb.m_xyz[(mb + j0) * 3 + k];
     }
     __syncthreads();
-    if (!wave_live) continue;
+    if (!wave_live) return;
     uint32_t quad[4] = {0u, 0u, 0u, 0u};
     for (int w0 = 0; w0 < nt; w0 += 32) {
       uint32_t word = 0, amb = 0;

@@ -94,6 +94,20 @@ struct PairBufs {
 };
 
 // image of pyramid level `lvl` of a slot
+// XCD-aware workgroup mapping.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in dispatch order,
+// so of a grid of nx work items for each of ny units (frames, pairs) the items of one unit would sit behind 8 different
+// L2s although they read the same images.  Within every group of 8 units the linear ids are re-dealt so that all items
+// of a unit are congruent mod 8 (same XCD); a tail of fewer than 8 units keeps the natural mapping.
+__device__ inline void xcd_map(int nx, int ny, int bx, int by, int* item, int* unit) {
+  const int lin = by * nx + bx, grp = lin / (8 * nx);
+  *item = bx; *unit = by;
+  if (grp * 8 + 8 <= ny) {
+    const int r = lin - grp * 8 * nx;
+    *unit = grp * 8 + (r & 7);
+    *item = r >> 3;
+  }
+}
+
 __device__ inline const uint8_t* level_img(const FrameBufs& fb, const FrameGeom& g, int slot, int lvl) {
   return lvl == 0 ? fb.l0_tab[slot] : fb.img + (size_t)slot * g.img_bytes + g.lv[lvl].img_off;
 }

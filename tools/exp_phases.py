@@ -24,6 +24,7 @@ slots = np.arange(2 * n_pairs, dtype=np.int32)
 L = _lib.load()
 names = ["stage", "phaseA", "phaseB", "nms", "compact", "nth", "lists+desc"]
 import time
+REPS = int(os.environ.get('EXP_REPS', '20'))
 have_abl = hasattr(L, "rvo_debug_fast_stop")  # only in -DRVO_PHASE_TIMING builds
 for stop in ((0, 1, 2, 3, 4, 5, 99) if have_abl else (99,)):  # ablation: k_fast_grid returns after phase `stop`; wall time of the whole prepare call
     if have_abl:
@@ -32,8 +33,8 @@ for stop in ((0, 1, 2, 3, 4, 5, 99) if have_abl else (99,)):  # ablation: k_fast
         ctx.prepare_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, slots)
     ctx.sync()
     t0 = time.perf_counter()
-    for _ in range(20):
+    for _ in range(REPS):
         ctx.prepare_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, slots)
     ctx.sync()
-    print("stop after", names[stop] if stop < 7 else "end", f"{(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per prepare call", flush=True)
+    print("stop after", names[stop] if stop < 7 else "end", f"{(time.perf_counter() - t0) / REPS * 1e3:.3f} ms per prepare call", flush=True)
 ctx.close()
