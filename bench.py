@@ -223,6 +223,16 @@ def main():
                         note="launch = one whole batch (512 frames / 256 pairs); launches of two batches in flight overlap, "
                              "so a launch's duration includes contention; the kernel is VALU-bound, not HBM-bound "
                              "(DESIGN.md section 5)")
+        # VALU issue roofline (the bound that actually holds for this path): issue time per batch from
+        # the committed SQ counters of this same command (a --pmc pass of its own) against the live batch time
+        roof_valu = None
+        sp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_sq_counters.csv")
+        if os.path.exists(sp) and n_pairs == 256 and n_ctx == 2 and not os.environ.get("RVO_PAIR_CHUNKS"):
+            import csv
+            issue_ms = sum(float(r["valu_issue_ms_at_2.4GHz"]) * int(r["launches_per_batch"]) for r in csv.DictReader(open(sp)))
+            roof_valu = dict(bound="valu-issue", issue_ms_per_batch=issue_ms, frac=issue_ms / (dt / a.steps * 1e3),
+                             source="profiles/r01_sq_counters.csv: SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz per launch, "
+                                    "summed over the launches of one batch")
         kernels = {k: dict(avg_ms=v["total_ms"] / v["calls"], calls=v["calls"],
                            GBps=(B[k] / (v["total_ms"] / v["calls"] * 1e-3) / 1e9) if k in B else None)
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
@@ -259,7 +269,7 @@ def main():
                     roofline=roof,
                     roofline_path=dict(bytes_per_pair=b_pair, frac=value / world * b_pair / HBM_PEAK,
                                        note="SURVEY 8(d) B_pair at the measured K and N, per GPU"),
-                    cpu_baseline=cpu, kernels=kernels, stats=stats,
+                    roofline_valu=roof_valu, cpu_baseline=cpu, kernels=kernels, stats=stats,
                     check=dict(pairs_success=ok, max_abs_pose_err_vs_truth=float(err)),
                     gather_ms=gather_ms, gather_backend=gather_backend)
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -37,3 +37,27 @@ for n, v in res["kernels"].items():
     print(n, v["launches"], v["traffic_bytes"])
 d = json.loads(line)
 print(d["value"], d["ms_per_step"], d["roofline"], d["cpu_baseline"]["value"])
+
+# SQ issue counters (a third --pmc pass, optional): where each kernel's wave cycles go
+import os
+sq = "gpurun_out/pmc_sq/s_counter_collection.csv"
+if os.path.exists(sq):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(sq)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    nb = len(acc["k_fast_grid"]["SQ_WAVE_CYCLES"])  # batches in the run
+    with open(f"profiles/r01_{tag}_sq_counters.csv", "w") as f:
+        f.write("kernel,launches_per_batch,SQ_INSTS_VALU,SQ_WAVE_CYCLES,valu_active_frac,inst_active_frac,wait_any_frac,wait_inst_frac,lds_active_frac,valu_issue_ms_at_2.4GHz\n")
+        for k, v in acc.items():
+            if k not in names:
+                continue
+            m = {c: sum(x) / len(x) for c, x in v.items()}
+            wc = m["SQ_WAVE_CYCLES"]
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs: x4 cycles / 1024 SIMDs / 2.4 GHz
+            ms = m["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / 2.4e9 * 1e3
+            f.write(f"{names[k]},{len(v['SQ_WAVE_CYCLES']) // nb},{m['SQ_INSTS_VALU']:.0f},{wc:.0f},{m['SQ_ACTIVE_INST_VALU'] / wc:.3f},"
+                    f"{m['SQ_ACTIVE_INST_ANY'] / wc:.3f},{m['SQ_WAIT_ANY'] / wc:.3f},{m['SQ_WAIT_INST_ANY'] / wc:.3f},"
+                    f"{m['SQ_ACTIVE_INST_LDS'] / wc:.3f},{ms:.4f}\n")
+    shutil.copy(f"profiles/r01_{tag}_sq_counters.csv", "profiles/r01_sq_counters.csv")  # the copy bench.py reads
+    print(open(f"profiles/r01_{tag}_sq_counters.csv").read())
