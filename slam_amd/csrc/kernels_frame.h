@@ -153,7 +153,10 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
     *reinterpret_cast<uint4*>(&s_src[r][16 * c16]) = v;
   }
   __syncthreads();
-  // pass 1: along x (source rows -> s_mid), what the reference stores transposed in pyrbuf
+  // pass 1: along x (source rows -> s_mid), what the reference stores transposed in pyrbuf.  Every group of four takes
+  // the packed interior formula (bytes outside the image were staged as zeros); the first and the last output of a
+  // line are then replaced by the reference's edge formulas (pyramid.cpp:67-99), so edge tiles pay one short patch
+  // instead of a scalar path for the whole wave.
   const int lastx = S.w / 2 - 1, lasty = S.h / 2 - 1;
   for (int i = tid; i < PYR_SROWS * (PYR_TW / 4); i += 256) {
     const int r = i / (PYR_TW / 4), x4 = (i % (PYR_TW / 4)) * 4;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
     uint2 out = make_uint2(0u, 0u);
     if (gy >= 0 && gy < S.h && ox < dw) {
       const uint8_t* row = s_src[r];
-      if (ox >= 1 && ox + 3 < lastx) {
+      {
         // bytes 2*x4+12 .. 2*x4+27 of the staged row; output ox+j reads bytes 2*x4 + 14 + 2j .. +4
         const uint32_t* rw = reinterpret_cast<const uint32_t*>(row + 2 * x4 + 12);
         const uint2 a = make_uint2(rw[0], rw[1]), c = make_uint2(rw[2], rw[3]);
@@ -172,35 +175,54 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
         const uint32_t o12 = __builtin_amdgcn_alignbit(O1, O0, 16), o34 = __builtin_amdgcn_alignbit(O2, O1, 16);
         out.x = ((e12 + e34 + 6u * E1 + 4u * (o12 + O1)) >> 4) & M;
         out.y = ((e34 + e56 + 6u * E2 + 4u * (o34 + O2)) >> 4) & M;
-      } else {
-        uint32_t v[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          v[j] = (ox + j < dw) ? (uint32_t)gauss_tap([&](int k) { return (int)row[k - sx0]; }, S.w, ox + j) : 0u;
-        out.x = v[0] | (v[1] << 16);
-        out.y = v[2] | (v[3] << 16);
+      }
+      const int je = lastx - ox;  // element of this group that is the last output of the line, if in 0..3
+      if (ox == 0 || (je >= 0 && je < 4)) {
+        auto at = [&](int k) { return (int)row[k - sx0]; };
+        if (ox == 0) out.x = (out.x & 0xFFFF0000u) | (uint32_t)gauss_tap(at, S.w, 0);
+        if (je >= 0 && je < 4 && lastx > 0) {
+          const uint32_t v = (uint32_t)gauss_tap(at, S.w, lastx);
+          if (je == 0) out.x = (out.x & 0xFFFF0000u) | v;
+          else if (je == 1) out.x = (out.x & 0x0000FFFFu) | (v << 16);
+          else if (je == 2) out.y = (out.y & 0xFFFF0000u) | v;
+          else out.y = (out.y & 0x0000FFFFu) | (v << 16);
+        }
       }
     }
     *reinterpret_cast<uint2*>(&s_mid[r][x4]) = out;
   }
   __syncthreads();
-  // pass 2: along y; thread = 4 adjacent outputs of one row
+  // pass 2: along y; thread = 4 adjacent outputs of one row.  Same scheme: packed interior formula (s_mid rows outside
+  // the image are zero), then the first / last output row takes the edge formula, also packed.
   for (int y = tid >> 4; y < PYR_TH; y += 16) {
     const int x4 = (tid & 15) * 4;
     const int ox = ox0 + x4, oy = oy0 + y;
     if (ox < dw && oy < dh) {
       uint8_t* drow = dst + (size_t)oy * D.stride + ox;
-      if (oy >= 1 && oy < lasty && ox + 3 < dw) {
-        uint2 A[5];
+      uint2 A[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) A[k] = *reinterpret_cast<const uint2*>(&s_mid[2 * y + k][x4]);  // rows 2*oy-2 .. 2*oy+2
-        const uint32_t r01 = ((A[0].x + A[4].x + 6u * A[2].x + 4u * (A[1].x + A[3].x)) >> 4) & M;
-        const uint32_t r23 = ((A[0].y + A[4].y + 6u * A[2].y + 4u * (A[1].y + A[3].y)) >> 4) & M;
+      for (int k = 0; k < 5; k++) A[k] = *reinterpret_cast<const uint2*>(&s_mid[2 * y + k][x4]);  // rows 2*oy-2 .. 2*oy+2
+      uint32_t r01 = ((A[0].x + A[4].x + 6u * A[2].x + 4u * (A[1].x + A[3].x)) >> 4) & M;
+      uint32_t r23 = ((A[0].y + A[4].y + 6u * A[2].y + 4u * (A[1].y + A[3].y)) >> 4) & M;
+      if (oy == 0) {  // rows 0,1,2 = A[2],A[3],A[4]: (s0 + 4 s1 + 3 s2) >> 3
+        r01 = ((A[2].x + 4u * A[3].x + 3u * A[4].x) >> 3) & M;
+        r23 = ((A[2].y + 4u * A[3].y + 3u * A[4].y) >> 3) & M;
+      } else if (oy == lasty) {  // o = 2*(lasty-1) = row A[0]
+        if (S.h & 1) {
+          r01 = ((3u * A[0].x + 4u * A[1].x + A[2].x) >> 3) & M;
+          r23 = ((3u * A[0].y + 4u * A[1].y + A[2].y) >> 3) & M;
+        } else {
+          r01 = ((A[0].x + 4u * A[1].x + 7u * A[2].x + 4u * A[3].x) >> 4) & M;
+          r23 = ((A[0].y + 4u * A[1].y + 7u * A[2].y + 4u * A[3].y) >> 4) & M;
+        }
+      }
+      if (ox + 3 < dw) {
         *reinterpret_cast<uint32_t*>(drow) = __builtin_amdgcn_perm(r23, r01, 0x06040200u);
       } else {
+        const uint32_t v[4] = {r01 & 0xFFu, r01 >> 16, r23 & 0xFFu, r23 >> 16};
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (ox + j < dw) drow[j] = (uint8_t)gauss_tap([&](int k) { return (int)s_mid[k - sy0][x4 + j]; }, S.h, oy);
+          if (ox + j < dw) drow[j] = (uint8_t)v[j];
       }
     }
   }

@@ -21,6 +21,8 @@ CONFIGS = [
     ((352, 288), dict(grid_width=33, grid_height=31, max_keypoints_per_grid=3, num_pyramid_levels=1,
                       inlier_max_reprojection_error=0.8, min_features_for_estimate=5), 20,
      "odd cells, one level (initial rotation on level 0), few keypoints per cell, harsh reprojection pruning"),
+    ((362, 250), dict(grid_width=45, grid_height=40, max_keypoints_per_grid=10, num_pyramid_levels=3), 15,
+     "odd level sizes (181x125 -> 90x62: the odd-length edge formulas of the pyramid in both directions)"),
 ]
 
 
