@@ -73,8 +73,8 @@ def algorithmic_bytes(geom: dict, stats: dict) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=256, help="independent frame pairs per GPU per step")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="passes over those pairs (about 10 s of CPU work in all)")

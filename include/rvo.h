@@ -111,6 +111,13 @@ const char* rvo_last_error(void);
  * HIP stream, see rvo_match_frames_dev).  Default 2 (env RVO_PAIR_CHUNKS overrides at rvo_create).  Use 1 when the
  * caller already keeps two batches in flight on two contexts (double buffering), which overlaps better. */
 int rvo_set_pair_chunks(rvo_ctx* ctx, int chunks);
+/* No counterpart in the reference either: for callers that keep batches in flight on two contexts of one device.
+ * Everything enqueued on ctx after this call waits until the frames last submitted on peer (rvo_match_frames_dev /
+ * rvo_prepare_frames*) have finished their FAST stage.  Called before every submit with the other context as peer it
+ * keeps the two batches apart: their VALU-bound FAST launches never run against each other and the image stages of one
+ * batch run beside the per-pair stages of the other (+2 % over free-running contexts, which drift into lockstep).
+ * A peer that has not submitted anything yet does not block. */
+int rvo_wait_peer(rvo_ctx* ctx, rvo_ctx* peer);
 /* Use an existing HIP stream (hipStream_t passed as void*; NULL = the context's own). */
 int rvo_set_stream(rvo_ctx* ctx, void* hip_stream);
 int rvo_sync(rvo_ctx* ctx);

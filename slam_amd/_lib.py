@@ -52,7 +52,7 @@ SYMBOLS = [
     "rvo_get_stream_slots",
     "rvo_get_level_info", "rvo_get_level_image", "rvo_get_grid_keypoints", "rvo_get_keypoints",
     "rvo_get_descriptors", "rvo_get_matches", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_read",
-    "rvo_selftest_stdalgo", "rvo_bgr_to_gray_dev", "rvo_depth_to_point_cloud_dev", "rvo_get_pair_information", "rvo_set_pair_chunks",
+    "rvo_selftest_stdalgo", "rvo_bgr_to_gray_dev", "rvo_depth_to_point_cloud_dev", "rvo_get_pair_information", "rvo_set_pair_chunks", "rvo_wait_peer",
 ]
 
 _LIB = None
@@ -74,6 +74,7 @@ def load():
     L.rvo_set_stream.argtypes = [vp, vp]
     L.rvo_sync.argtypes = [vp]
     L.rvo_set_pair_chunks.argtypes = [vp, ip]
+    L.rvo_wait_peer.argtypes = [vp, vp]
     L.rvo_prepare_frames.argtypes = [vp, ip, vp, vp, vp, vp]
     L.rvo_prepare_frames_dev.argtypes = [vp, ip, vp, vp, vp, vp]
     L.rvo_match_pairs.argtypes = [vp, ip, vp, vp, vp, vp]

@@ -7,6 +7,7 @@
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 
 import numpy as np
@@ -149,6 +150,10 @@ class Context:
 
     def set_pair_chunks(self, chunks: int):
         self._chk(self.L.rvo_set_pair_chunks(self.h, chunks))
+
+    def wait_peer(self, peer: "Context"):
+        """What is enqueued next waits until the FAST stage of peer's batch in flight is done (rvo_wait_peer)."""
+        self._chk(self.L.rvo_wait_peer(self.h, peer.h))
 
     def pair_information(self, n):
         """info = cov.inverse() of the first n pair results (pose_graph.cpp:265), [n, 6, 6]; zeros where not SUCCESS."""
@@ -327,10 +332,14 @@ class PipelinedFrameMatcher:
                 c.set_pair_chunks(1)
         self.slots = np.arange(2 * n_pairs, dtype=np.int32)
         self.k = 0
+        self.stagger = os.environ.get("RVO_STAGGER", "1") != "0"  # rvo_wait_peer before every submit (+2 %)
 
     def submit(self, gray_ptr: int, depth_ptr: int, fast_thr, init_pose=None) -> int:
         """Enqueue one batch (frames 2i, 2i+1 -> pair i).  Returns the ticket results() takes."""
-        self.ctxs[self.k % len(self.ctxs)].match_frames_dev(gray_ptr, depth_ptr, fast_thr, self.slots, init_pose)
+        c = self.ctxs[self.k % len(self.ctxs)]
+        if self.stagger and len(self.ctxs) > 1:
+            c.wait_peer(self.ctxs[(self.k - 1) % len(self.ctxs)])
+        c.match_frames_dev(gray_ptr, depth_ptr, fast_thr, self.slots, init_pose)
         self.k += 1
         return self.k - 1
 

@@ -70,6 +70,7 @@ struct rvo_ctx {
   static const int kAux = 3;
   hipStream_t aux[kAux] = {};
   hipEvent_t ev_fork = nullptr, ev_join[kAux] = {};
+  hipEvent_t ev_mid = nullptr;  // recorded after k_fast_grid of a batch (rvo_wait_peer)
   int pair_chunks = 2;
   // profiling
   bool prof = false;
@@ -264,6 +265,7 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
     HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
   }
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
   for (int i = 0; i < 2; i++) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_pyr[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_rot[i], hipEventDisableTiming));
@@ -335,6 +337,7 @@ void rvo_destroy(rvo_ctx* c) {
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   for (int i = 0; i < 2; i++) {
     if (c->ev_pyr[i]) (void)hipEventDestroy(c->ev_pyr[i]);
     if (c->ev_rot[i]) (void)hipEventDestroy(c->ev_rot[i]);
@@ -405,6 +408,7 @@ static int enqueue_pyramid_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* 
 static int enqueue_features_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots, const int32_t* d_thr) {
   const FrameGeom& g = c->g;
   LAUNCH_ON(c, st, "fast_grid", k_fast_grid, dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
+  if (st == c->stream) HIPCHK(hipEventRecord(c->ev_mid, st));  // rvo_wait_peer
   LAUNCH_ON(c, st, "build_keypoints", k_build_keypoints, dim3(g.levels, n), dim3(256), 0, c->fb, g, d_slots);
   LAUNCH_ON(c, st, "descriptors", k_descriptors, dim3((g.kp_total * 5 + 255) / 256, n), dim3(256), 0, c->fb, g, d_slots);
   HIPCHK(hipGetLastError());
