@@ -883,16 +883,18 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
       }
       if (j0 + w0 >= jstart + 256) {
         // transpose: lane b collects the 64-bit column (rows iw0..iw0+63) of column j0+w0+b
-        unsigned long long col = 0;
+        // (the ballots are scalar values: v_writelane drops each into its lane, no per-lane select)
+        uint32_t col_lo = 0, col_hi = 0;
 #pragma unroll
         for (int b = 0; b < 32; b++) {
-          const unsigned long long m = __ballot((word >> b) & 1u);
-          if (lane == b) col = m;
+          const unsigned long long m = __ballot((word & (1u << b)) != 0u);
+          col_lo = __llvm_amdgcn_writelane((uint32_t)m, b, col_lo);
+          col_hi = __llvm_amdgcn_writelane((uint32_t)(m >> 32), b, col_hi);
         }
         const int jc = j0 + w0 + lane;
         if (lane < 32 && jc < N) {
           // iw0 is a multiple of 64 and cwords a multiple of 4: both words exist and the pair is 8-byte aligned
-          *reinterpret_cast<uint2*>(pb.cbits + (mb + jc) * pb.cwords + (iw0 >> 5)) = make_uint2((uint32_t)col, (uint32_t)(col >> 32));
+          *reinterpret_cast<uint2*>(pb.cbits + (mb + jc) * pb.cwords + (iw0 >> 5)) = make_uint2(col_lo, col_hi);
         }
       }
     }

@@ -94,6 +94,10 @@ struct PairBufs {
 };
 
 // image of pyramid level `lvl` of a slot
+// v_writelane_b32 (clang has no builtin for it; the LLVM intrinsic is reached through its assembler name, and the
+// compiler schedules it and its hazards like any other instruction): lane `lane` of `old` := the scalar `val`.
+extern "C" __device__ unsigned __llvm_amdgcn_writelane(unsigned val, unsigned lane, unsigned old) __asm("llvm.amdgcn.writelane.i32");
+
 // XCD-aware workgroup mapping.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in dispatch order,
 // so of a grid of nx work items for each of ny units (frames, pairs) the items of one unit would sit behind 8 different
 // L2s although they read the same images.  Within every group of 8 units the linear ids are re-dealt so that all items
