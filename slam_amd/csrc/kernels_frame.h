@@ -380,21 +380,36 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   const int shx = cx0 - 4 - gx0;      // 0..15: columns between the first loaded byte and the tile's first column
   const int shl = shx & 3, sd = shx >> 2, tdw = TP / 4;
   {
-    const int t16 = (shx + cw + 8 + 15) >> 4;  // 16-byte words per row
-    const int q = 256 / t16, rr = 256 % t16;
-    int r = tid / t16, c = tid % t16;
-    while (r < trows) {
-      const int gy = gy0 + r, gx = gx0 + 16 * c;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (gy >= 0 && gy < G.h && gx >= 0 && gx < G.stride) v = *reinterpret_cast<const uint4*>(img + (size_t)gy * G.stride + gx);
-      uint32_t* drow = reinterpret_cast<uint32_t*>(s_tile + r * TP);
-      const int d0 = 4 * c - sd;
-      if (d0 >= 0 && d0 < tdw) drow[d0] = v.x;
-      if (d0 + 1 >= 0 && d0 + 1 < tdw) drow[d0 + 1] = v.y;
-      if (d0 + 2 >= 0 && d0 + 2 < tdw) drow[d0 + 2] = v.z;
-      if (d0 + 3 >= 0 && d0 + 3 < tdw) drow[d0 + 3] = v.w;
-      c += rr; r += q;
-      if (c >= t16) { c -= t16; r++; }
+    // thread = (column word c, row r0s) with c fixed: the column's bounds and store guards are computed once, rows advance
+    // by 256 / t16 per pass; three loads are in flight before their stores
+    const int t16 = (shx + cw + 8 + 15) >> 4;  // 16-byte words per row (<= 18: cells are at most 253 wide)
+    const int rpp = 256 / t16;                 // rows per pass
+    const int r0s = (tid * ((65536 + t16 - 1) / t16)) >> 16, c = tid - r0s * t16;  // tid / t16, tid % t16 (exact for tid < 256)
+    const int gx = gx0 + 16 * c;
+    const int d0 = 4 * c - sd;
+    const bool colok = gx >= 0 && gx < G.stride;
+    const bool w0 = d0 >= 0 && d0 < tdw, w1 = d0 + 1 >= 0 && d0 + 1 < tdw, w2 = d0 + 2 >= 0 && d0 + 2 < tdw, w3 = d0 + 3 >= 0 && d0 + 3 < tdw;
+    const uint8_t* __restrict__ src = img + gx;
+    if (r0s < rpp) {
+      for (int r = r0s; r < trows; r += 3 * rpp) {
+        uint4 v[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+          const int gy = gy0 + r + u * rpp;
+          v[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (colok && r + u * rpp < trows && gy >= 0 && gy < G.h) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)gy * G.stride);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+          if (r + u * rpp < trows) {
+            uint32_t* drow = reinterpret_cast<uint32_t*>(s_tile + (r + u * rpp) * TP) + d0;
+            if (w0) drow[0] = v[u].x;
+            if (w1) drow[1] = v[u].y;
+            if (w2) drow[2] = v[u].z;
+            if (w3) drow[3] = v[u].w;
+          }
+        }
+      }
     }
   }
   // ---- FAST, phase A: cheap necessary test on the 4 compass ring pixels for every pixel of the cell + 1 px halo.
