@@ -661,7 +661,14 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     const double s00 = S00, s01 = S01, s11 = S11;
     const double det = s00 * s11 - s01 * s01;
     if (det <= 1e-9) break;
-    const double si00 = s11 / det, si01 = -s01 / det, si11 = s00 / det;
+    // the three quotients share the denominator: one refined reciprocal, then the same last steps as the correctly
+    // rounded fp64 division sequence (q = n*r; q += fma(-det, q, n) * r).  det is an integer in [1, 2^50) and the
+    // numerators are integers below 2^25, so none of that sequence's scaling / fix-up cases can occur.
+    double rc = __builtin_amdgcn_rcp(det);
+    rc = __builtin_fma(__builtin_fma(-det, rc, 1.0), rc, rc);
+    rc = __builtin_fma(__builtin_fma(-det, rc, 1.0), rc, rc);
+    auto quot = [&](double nmr) { const double q = nmr * rc; return __builtin_fma(__builtin_fma(-det, q, nmr), rc, q); };
+    const double si00 = quot(s11), si01 = quot(-s01), si11 = quot(s00);
     const double gx = gxs, gy = gys;
     const double dxs = -2 * (si00 * gx + si01 * gy);
     const double dys = -2 * (si01 * gx + si11 * gy);
