@@ -637,14 +637,14 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     tsum += traw[m];
   }
   const int rmean = group16_sum(rsum) / RVO_DESC_LEN;
-  int tmean = group16_sum(tsum) / RVO_DESC_LEN;
-  int rn[REFINE_TAPS];
+  const int tmean = group16_sum(tsum) / RVO_DESC_LEN;
+  int rn[REFINE_TAPS], te[REFINE_TAPS];  // te = error of the current target descriptor against the reference's
   int final_sse = 0;
 #pragma unroll
   for (int m = 0; m < REFINE_TAPS; m++) {
     rn[m] = norm_px(rraw[m], rmean);
-    const int e = norm_px(traw[m], tmean) - rn[m];
-    final_sse += e * e;
+    te[m] = norm_px(traw[m], tmean) - rn[m];
+    final_sse += te[m] * te[m];
   }
   final_sse = group16_sum(final_sse);
   const int min_xy = RVO_WIN, max_x = G.w - RVO_WIN - 2, max_y = G.h - RVO_WIN - 2;  // pyramid.cpp:123-126
@@ -654,8 +654,7 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
     for (int m = 0; m < REFINE_TAPS; m++) {
       const int mx = rdx[m] + (tnb[m].p01 - tnb[m].p00);
       const int my = rdy[m] + (tnb[m].p10 - tnb[m].p00);
-      const int e = norm_px(traw[m], tmean) - rn[m];
-      S00 += mx * mx; S01 += mx * my; S11 += my * my; gxs += mx * e; gys += my * e;
+      S00 += mx * mx; S01 += mx * my; S11 += my * my; gxs += mx * te[m]; gys += my * te[m];
     }
     S00 = group16_sum(S00); S01 = group16_sum(S01); S11 = group16_sum(S11); gxs = group16_sum(gxs); gys = group16_sum(gys);
     const double s00 = S00, s01 = S01, s11 = S11;
@@ -682,17 +681,17 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
 #pragma unroll
     for (int m = 0; m < REFINE_TAPS; m++) { nraw[m] = interp(wn, m, nnb[m]); nsum += nraw[m]; }
     const int nmean = group16_sum(nsum) / RVO_DESC_LEN;
-    int sse = 0;
+    int sse = 0, ne[REFINE_TAPS];
 #pragma unroll
     for (int m = 0; m < REFINE_TAPS; m++) {
-      const int e = norm_px(nraw[m], nmean) - rn[m];
-      sse += e * e;
+      ne[m] = norm_px(nraw[m], nmean) - rn[m];
+      sse += ne[m] * ne[m];
     }
     sse = group16_sum(sse);
     if (sse < final_sse) {
-      tx = ntx; ty = nty; final_sse = sse; tmean = nmean;
+      tx = ntx; ty = nty; final_sse = sse;
 #pragma unroll
-      for (int m = 0; m < REFINE_TAPS; m++) { traw[m] = nraw[m]; tnb[m] = nnb[m]; }
+      for (int m = 0; m < REFINE_TAPS; m++) { te[m] = ne[m]; tnb[m] = nnb[m]; }
     } else break;
     if (fabs(dxs) < 0.1 && fabs(dys) < 0.1) break;
   }
