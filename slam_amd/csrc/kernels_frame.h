@@ -626,6 +626,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   FAST_PHASE(3);  // NMS
   // ---- raster-ordered compaction of the bitmap (the order the reference pushes keypoints into the bucket)
   int total = 0, base_run = 0;
+  const uint32_t inv_cw = 0xFFFFFFFFu / (uint32_t)cw + 1u;  // idx / cw == umulhi(idx, inv_cw) for idx < 2^16, cw < 2^8
   for (int w0 = 0; w0 < nwords; w0 += 256) {
     const int w = w0 + tid;
     uint32_t word = w < nwords ? s_bits[w] : 0u;
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
       const int bit = __ffs(word) - 1;
       word &= word - 1;
       const int idx = (w << 5) + bit;
-      const int y = idx / cw, x = idx - y * cw;
+      const int y = (int)__umulhi((uint32_t)idx, inv_cw), x = idx - y * cw;
       if (pos < L.list_cap) s_list[pos] = kp_pack(cx0 + x, cy0 + y, s_score[(y + 1) * SP + (x + 1)] - 1);
       pos++;
     }
