@@ -70,6 +70,7 @@ struct rvo_ctx {
   static const int kAux = 3;
   hipStream_t aux[kAux] = {};
   hipEvent_t ev_fork = nullptr, ev_join[kAux] = {};
+  bool rot_side = true;  // k_init_rotation on a side stream (env RVO_ROT_SIDE=0: on the batch's own stream)
   hipEvent_t ev_mid = nullptr;  // recorded after k_fast_grid of a batch (rvo_wait_peer)
   int pair_chunks = 2;
   // profiling
@@ -266,6 +267,7 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   }
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
+  if (const char* e = getenv("RVO_ROT_SIDE")) c->rot_side = atoi(e) != 0;
   for (int i = 0; i < 2; i++) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_pyr[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_rot[i], hipEventDisableTiming));
