@@ -165,16 +165,17 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
     if (gy >= 0 && gy < S.h && ox < dw) {
       const uint8_t* row = s_src[r];
       {
-        // bytes 2*x4+12 .. 2*x4+27 of the staged row; output ox+j reads bytes 2*x4 + 14 + 2j .. +4
+        // bytes b0..b15 = 2*x4+12 .. 2*x4+27 of the staged row; output ox+j is the 1-4-6-4-1 sum of b[2+2j .. 6+2j].
+        // v_dot4_u32_u8 with the taps scaled by 16 (16 64 96 64 16): byte 1 of the 16-bit result is the sum >> 4, so one
+        // v_perm_b32 packs two outputs into the u16 pair the second pass reads.
         const uint32_t* rw = reinterpret_cast<const uint32_t*>(row + 2 * x4 + 12);
-        const uint2 a = make_uint2(rw[0], rw[1]), c = make_uint2(rw[2], rw[3]);
-        const uint32_t E0 = a.x & M, E1 = a.y & M, E2 = c.x & M, E3 = c.y & M;                            // even bytes, pairs
-        const uint32_t O0 = (a.x >> 8) & M, O1 = (a.y >> 8) & M, O2 = (c.x >> 8) & M;                     // odd bytes
-        const uint32_t e12 = __builtin_amdgcn_alignbit(E1, E0, 16), e34 = __builtin_amdgcn_alignbit(E2, E1, 16);
-        const uint32_t e56 = __builtin_amdgcn_alignbit(E3, E2, 16);
-        const uint32_t o12 = __builtin_amdgcn_alignbit(O1, O0, 16), o34 = __builtin_amdgcn_alignbit(O2, O1, 16);
-        out.x = ((e12 + e34 + 6u * E1 + 4u * (o12 + O1)) >> 4) & M;
-        out.y = ((e34 + e56 + 6u * E2 + 4u * (o34 + O2)) >> 4) & M;
+        const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2], d3 = rw[3];
+        const uint32_t o0 = __builtin_amdgcn_udot4(d1, 0x00104060u, __builtin_amdgcn_udot4(d0, 0x40100000u, 0u, false), false);  // b2 b3 | b4 b5 b6
+        const uint32_t o1 = __builtin_amdgcn_udot4(d2, 0x00000010u, __builtin_amdgcn_udot4(d1, 0x40604010u, 0u, false), false);  // b4..b7 | b8
+        const uint32_t o2 = __builtin_amdgcn_udot4(d2, 0x00104060u, __builtin_amdgcn_udot4(d1, 0x40100000u, 0u, false), false);  // b6 b7 | b8 b9 b10
+        const uint32_t o3 = __builtin_amdgcn_udot4(d3, 0x00000010u, __builtin_amdgcn_udot4(d2, 0x40604010u, 0u, false), false);  // b8..b11 | b12
+        out.x = __builtin_amdgcn_perm(o1, o0, 0x0C050C01u);
+        out.y = __builtin_amdgcn_perm(o3, o2, 0x0C050C01u);
       }
       const int je = lastx - ox;  // element of this group that is the last output of the line, if in 0..3
       if (ox == 0 || (je >= 0 && je < 4)) {
