@@ -135,17 +135,35 @@ def main():
             c.sync()
         torch.cuda.synchronize()
 
+    def read_prof():
+        acc = {}
+        for c in ctxs:
+            for name, v in c.profile_read().items():
+                e = acc.setdefault(name, dict(total_ms=0.0, calls=0))
+                e["total_ms"] += v["total_ms"]
+                e["calls"] += v["calls"]
+        return acc
+
+    # Warm-up.  With HIP events around all ~15 launches of a batch the pipeline runs about 7 % slower, so the warm-up
+    # (events around every launch) only finds the dominant kernel; the timed region then brackets that kernel alone.
+    noprof = bool(os.environ.get("RVO_BENCH_NOPROF"))
+    if not noprof:
+        for c in ctxs:
+            c.profile_enable(True)
     for k in range(a.warmup):
         step(k)
     sync_all()
+    dom = None
+    if not noprof:
+        wp = read_prof()
+        dom = max(wp, key=lambda k: wp[k]["total_ms"]) if wp else None
+        for c in ctxs:
+            c.profile_enable(dom is not None, only=dom)  # also clears the accumulated records
 
     def barrier():
         if world > 1:
             dist.all_reduce(torch.zeros(1))  # CPU tensor -> gloo
 
-    if not os.environ.get("RVO_BENCH_NOPROF"):
-        for c in ctxs:
-            c.profile_enable(True)  # HIP events around every launch, on the stream the kernels run on
     barrier()
     sync_all()
     t0 = time.perf_counter()
@@ -154,13 +172,19 @@ def main():
     sync_all()
     barrier()
     dt = time.perf_counter() - t0
+    prof_dom = read_prof() if not noprof else {}  # the dominant kernel over the timed region, on its own stream
+    # the other kernels' durations (the `kernels` table): a separate pass after the timed region, events around every launch
     prof = {}
-    for c in ctxs:
-        for name, v in c.profile_read().items():
-            acc = prof.setdefault(name, dict(total_ms=0.0, calls=0))
-            acc["total_ms"] += v["total_ms"]
-            acc["calls"] += v["calls"]
-        c.profile_enable(False)
+    post_steps = min(a.steps, 20)
+    if not noprof:
+        for c in ctxs:
+            c.profile_enable(True)
+        for k in range(post_steps):
+            step(a.warmup + a.steps + k)
+        sync_all()
+        prof = read_prof()
+        for c in ctxs:
+            c.profile_enable(False)
     ctx = pipe.context_of(pipe.k - 1)  # holds the last batch's results
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
@@ -202,11 +226,10 @@ def main():
         for k in list(B):  # the batch runs as stream chunks: scale to what ONE launch of the kernel processes
             if k in prof:
                 base = (geom["levels"] - 1) if k == "pyr_down" else 1
-                B[k] = B[k] / max(1.0, prof[k]["calls"] / (a.steps * base))
-        dom = max(prof, key=lambda k: prof[k]["total_ms"]) if prof else None
+                B[k] = B[k] / max(1.0, prof[k]["calls"] / (post_steps * base))
         roof = None
-        if dom and dom in B:
-            avg_s = prof[dom]["total_ms"] / prof[dom]["calls"] * 1e-3
+        if dom and dom in B and dom in prof_dom:
+            avg_s = prof_dom[dom]["total_ms"] / prof_dom[dom]["calls"] * 1e-3
             ach = B[dom] / avg_s
             # HBM traffic per launch: not measurable from inside this process; taken from the committed rocprofv3
             # --pmc passes of this same command (profiles/r01_pmc_traffic.json), valid for the default launch shape
@@ -219,6 +242,7 @@ def main():
                     traffic_src = "profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, separate --pmc passes"
             roof = dict(bound="hbm", kernel=dom, achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                         frac=ach / HBM_PEAK, traffic=traffic, traffic_source=traffic_src, avg_launch_ms=avg_s * 1e3,
+                        launches_timed=prof_dom[dom]["calls"],
                         algorithmic_bytes_per_launch=B[dom],
                         note="launch = one whole batch (512 frames / 256 pairs); launches of two batches in flight overlap, "
                              "so a launch's duration includes contention; the kernel is VALU-bound, not HBM-bound "
@@ -269,7 +293,10 @@ def main():
                     roofline=roof,
                     roofline_path=dict(bytes_per_pair=b_pair, frac=value / world * b_pair / HBM_PEAK,
                                        note="SURVEY 8(d) B_pair at the measured K and N, per GPU"),
-                    roofline_valu=roof_valu, cpu_baseline=cpu, kernels=kernels, stats=stats,
+                    roofline_valu=roof_valu, cpu_baseline=cpu, kernels=kernels,
+                    kernels_steps=post_steps,
+                    kernels_note=f"separate pass of {post_steps} steps after the timed region with HIP events around every launch "
+                                 "(that instrumentation costs about 7 %); the timed region brackets only the dominant kernel", stats=stats,
                     check=dict(pairs_success=ok, max_abs_pose_err_vs_truth=float(err)),
                     gather_ms=gather_ms, gather_backend=gather_backend)
         os.write(json_fd, (json.dumps(line) + "\n").encode())

@@ -207,6 +207,9 @@ int rvo_selftest_stdalgo(int device, const uint32_t* keys, int n, int shift, int
 /* ---- measurement support ---- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
 int rvo_profile_enable(rvo_ctx* ctx, int on);
+/* Restricts the bracketing to launches of one kernel ("fast_grid", "refine", ...; NULL = all again): two events per
+ * batch instead of thirty, so that a timed region can measure its dominant kernel without slowing the pipeline down. */
+int rvo_profile_select(rvo_ctx* ctx, const char* kernel_name);
 /* names/ms/calls arrays of capacity cap; returns the number of kernel kinds (accumulated since enable). */
 int rvo_profile_read(rvo_ctx* ctx, int cap, const char** names, float* total_ms, int32_t* calls);
 

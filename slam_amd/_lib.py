@@ -51,7 +51,7 @@ SYMBOLS = [
     "rvo_stream_step", "rvo_stream_step_dev", "rvo_get_stream_results", "rvo_stream_results_dev",
     "rvo_get_stream_slots",
     "rvo_get_level_info", "rvo_get_level_image", "rvo_get_grid_keypoints", "rvo_get_keypoints",
-    "rvo_get_descriptors", "rvo_get_matches", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_read",
+    "rvo_get_descriptors", "rvo_get_matches", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_select", "rvo_profile_read",
     "rvo_selftest_stdalgo", "rvo_bgr_to_gray_dev", "rvo_depth_to_point_cloud_dev", "rvo_get_pair_information", "rvo_set_pair_chunks", "rvo_wait_peer",
 ]
 
@@ -99,6 +99,7 @@ def load():
     L.rvo_get_matches.argtypes = [vp, ip, ip, vp, vp]
     L.rvo_get_lut.argtypes = [vp, vp, vp]
     L.rvo_profile_enable.argtypes = [vp, ip]
+    L.rvo_profile_select.argtypes = [vp, C.c_char_p]
     L.rvo_profile_read.argtypes = [vp, ip, vp, vp, vp]
     L.rvo_selftest_stdalgo.argtypes = [ip, vp, ip, ip, ip, vp]
     L.rvo_default_vo_params.argtypes = [C.POINTER(Params)]

@@ -244,7 +244,9 @@ class Context:
         return p.value
 
     # -- profiling
-    def profile_enable(self, on=True):
+    def profile_enable(self, on=True, only: str | None = None):
+        """HIP events around every launch, or only around launches of the kernel `only`."""
+        self._chk(self.L.rvo_profile_select(self.h, only.encode() if only else None))
         self._chk(self.L.rvo_profile_enable(self.h, 1 if on else 0))
 
     def profile_read(self):

@@ -75,6 +75,7 @@ struct rvo_ctx {
   int pair_chunks = 2;
   // profiling
   bool prof = false;
+  std::string prof_only;  // rvo_profile_select: bracket only launches of this kernel ("" = all)
   std::vector<std::string> prof_names;
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
@@ -136,14 +137,15 @@ static void prof_drain(rvo_ctx* c) {
 #define LAUNCH_ON(c, STREAM, NAME, KERNEL, GRID, BLOCK, SHMEM, ...)                       \
   do {                                                                                    \
     ProfRec pr_;                                                                          \
-    if ((c)->prof) {                                                                      \
+    const bool prof_ = (c)->prof && ((c)->prof_only.empty() || (c)->prof_only == NAME);   \
+    if (prof_) {                                                                          \
       pr_.name = prof_id((c), NAME);                                                      \
       pr_.a = get_event(c);                                                               \
       pr_.b = get_event(c);                                                               \
       (void)hipEventRecord(pr_.a, (STREAM));                                              \
     }                                                                                     \
     hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, (STREAM), __VA_ARGS__);                \
-    if ((c)->prof) {                                                                      \
+    if (prof_) {                                                                          \
       (void)hipEventRecord(pr_.b, (STREAM));                                              \
       (c)->prof_recs.push_back(pr_);                                                      \
     }                                                                                     \
@@ -542,6 +544,12 @@ int rvo_profile_enable(rvo_ctx* c, int on) {
   prof_drain(c);
   c->prof_acc.clear();
   c->prof = on != 0;
+  return RVO_OK;
+}
+
+int rvo_profile_select(rvo_ctx* c, const char* kernel_name) {
+  if (!c) return RVO_E_INVALID;
+  c->prof_only = kernel_name ? kernel_name : "";
   return RVO_OK;
 }
 

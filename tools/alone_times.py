@@ -10,4 +10,4 @@ out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu"
 d = json.loads(out.stdout.strip().splitlines()[-1])
 print(f"{d['value']:.0f} pairs/s, {d['ms_per_step']:.3f} ms/step (one context)")
 for k, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["avg_ms"] * kv[1]["calls"]):
-    print(f"  {k:16s} {v['avg_ms'] * v['calls'] / d['steps']:.3f} ms/step ({v['calls'] // d['steps']} launches)")
+    print(f"  {k:16s} {v['avg_ms'] * v['calls'] / d['kernels_steps']:.3f} ms/step ({v['calls'] // d['kernels_steps']} launches)")
