@@ -38,11 +38,14 @@ if __name__ == "__main__":
     def step(k):
         t = order[k % len(order)]
         for i, c in enumerate(ctxs):
+            if NC > 1:
+                c.wait_peer(ctxs[i - 1])  # starts when the other group's FAST stage is done
             c.stream_step_dev(dg[t, i * per:].data_ptr(), dd[t, i * per:].data_ptr(), per)
     for k in range(6): step(k)
     for c in ctxs: c.sync()
-    for c in ctxs: c.profile_enable(True)
-    n = 30
+    PROF = bool(os.environ.get("RVO_STREAMS_PROF"))  # HIP events around every launch cost several percent
+    for c in ctxs: c.profile_enable(PROF)
+    n = 60
     t0 = time.perf_counter()
     for k in range(6, 6 + n): step(k)
     for c in ctxs: c.sync()
