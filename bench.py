@@ -265,6 +265,7 @@ def main():
         b_frame = 640 * 480 + 2 * (320 * 240 + 160 * 120) + 128 * K + 4 * K
         b_pair = 2 * b_frame + 160 * K + N * N / 4
         cpu = None
+        cpu_multi = None
         if world == 1 and not a.no_cpu:
             from oracle.pyoracle import Oracle, default_params as odef
             orc = Oracle(intr, odef(frame_matcher=True))
@@ -280,6 +281,27 @@ def main():
                         same += (ro["num_matches"] == res[i]["num_matches"] and ro["num_inliers"] == res[i]["num_inliers"]
                                  and ro["status"] == res[i]["status"])
             cdt = time.perf_counter() - c0
+            # the same oracle on the host cores this process may use (independent pairs, one Oracle per thread; the
+            # library calls release the GIL): SURVEY 8(d)(ii)'s "N independent streams on N cores" leg
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+            oracles = [Oracle(intr, odef(frame_matcher=True)) for _ in range(nthr)]
+
+            mreps = 8 * a.cpu_reps  # about as much wall time as the single-thread leg
+
+            def cpu_worker(t):
+                o = oracles[t]
+                for rep in range(mreps):
+                    for i in range(t, m, nthr):
+                        o.prepare(0, gray[2 * i], depth[2 * i], thr)
+                        o.prepare(1, gray[2 * i + 1], depth[2 * i + 1], thr)
+                        o.match_pair(0, 1)
+            m0 = time.perf_counter()
+            with ThreadPoolExecutor(nthr) as ex:
+                list(ex.map(cpu_worker, range(nthr)))
+            mdt = time.perf_counter() - m0
+            cpu_multi = dict(value=m * mreps / mdt, unit="frame-pairs/s", cores=nthr, kind="port",
+                             sample=f"the same {m} pairs x {mreps} passes split over {nthr} threads ({mdt:.1f} s), one oracle instance per thread")
             cpu = dict(value=m * a.cpu_reps / cdt, unit="frame-pairs/s", cores=1, kind="port",
                        sample=f"first {m} of the same {n_pairs} pairs x {a.cpu_reps} passes ({cdt:.1f} s), oracle/librvo_oracle.so single thread; "
                               f"{same}/{m} pairs have identical match/inlier counts and status to the GPU result")
@@ -293,7 +315,7 @@ def main():
                     roofline=roof,
                     roofline_path=dict(bytes_per_pair=b_pair, frac=value / world * b_pair / HBM_PEAK,
                                        note="SURVEY 8(d) B_pair at the measured K and N, per GPU"),
-                    roofline_valu=roof_valu, cpu_baseline=cpu, kernels=kernels,
+                    roofline_valu=roof_valu, cpu_baseline=cpu, cpu_baseline_all_cores=cpu_multi, kernels=kernels,
                     kernels_steps=post_steps,
                     kernels_note=f"separate pass of {post_steps} steps after the timed region with HIP events around every launch "
                                  "(that instrumentation costs about 7 %); the timed region brackets only the dominant kernel", stats=stats,
