@@ -153,7 +153,7 @@ __device__ inline void block_sum_d(double* v, double* s_red) {
 
 // Same sum for the latency-bound single-block kernels: N values per thread are parked in LDS ([N][256] doubles),
 // N*8 threads add 32 of them each (rotated start: lanes hit different banks), thread 0 adds the 8 partials.
-// Fixed order, so results are deterministic.  Result valid in thread 0 only.  s_big: N*256 + N*8 doubles.
+// Fixed order, so results are deterministic.  Result valid in thread 0 only.  s_big: N*256 + N*16 doubles; NT >= N*16.
 // NT = block size (multiple of 256).
 template <int N, int NT>
 __device__ inline void block_sum_lds(double* v, double* s_big) {
@@ -171,20 +171,25 @@ __device__ inline void block_sum_lds(double* v, double* s_big) {
     }
     __syncthreads();
   }
-  if (tid < N * 8) {
-    const double* seg = s_big + tid * 32;
+  if (tid < N * 16) {  // 16 threads per value, each folds 16 slots (rotated start: no bank conflicts)
+    const double* seg = s_big + tid * 16;
     double s = 0;
-#pragma unroll 8
-    for (int j = 0; j < 32; j++) s += seg[(j + tid) & 31];
+#pragma unroll
+    for (int j = 0; j < 16; j++) s += seg[(j + tid) & 15];
     s_part[tid] = s;
+  }
+  __syncthreads();
+  if (tid < N) {  // one thread per value folds its 16 partials; the front of s_big is free again
+    const double* q = s_part + tid * 16;
+    double s = q[0];
+#pragma unroll
+    for (int j = 1; j < 16; j++) s += q[j];
+    s_big[tid] = s;
   }
   __syncthreads();
   if (tid == 0) {
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      const double* q = s_part + i * 8;
-      v[i] = ((((((q[0] + q[1]) + q[2]) + q[3]) + q[4]) + q[5]) + q[6]) + q[7];
-    }
+    for (int i = 0; i < N; i++) v[i] = s_big[i];
   }
 }
 
@@ -1199,7 +1204,7 @@ struct GnShared {
 // hoisted into registers the kernel needed 502 and could only run one).
 __global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, EstParams ep) {
   __shared__ GnShared S;
-  __shared__ double s_big[27 * 256 + 27 * 8];
+  __shared__ double s_big[27 * 256 + 27 * 16];
   const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x;
   if (!pb.active[pair]) return;
   const int N = pb.n_matches[pair];
@@ -1236,7 +1241,53 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, E
   };
 
   // refineMotionEstimate() -> refineMotionEstimateBidirectional, motion_estimate.cpp:610-682, 1208-1331
-  auto refine = [&]() {
+  // covariance = (M'M)^-1 at the current parameters S.est, motion_estimate.cpp:1319-1329
+  auto covariance = [&]() {
+    __syncthreads();
+    if (tid == 0) forward_jac_mats(S.est, fx, px, py, S.jac[0]);
+    if (tid == 64) reverse_jac_mats(S.est, fx, px, py, S.jac[1]);
+    __syncthreads();
+    double acc[21];
+#pragma unroll
+    for (int k = 0; k < 21; k++) acc[k] = 0;
+    for (int item = tid; item < 2 * N; item += GN_THREADS) {
+      const int i = item >> 1, dir = item & 1;
+      if (!pb.m_inlier[mb + i]) continue;
+      {
+        const JacMats& J = S.jac[dir];
+        const double* pt = (dir ? pb.m_rxyz : pb.m_xyz) + (mb + i) * 3;
+        const double x = pt[0], y = pt[1], z = pt[2];
+        const double u = dot4(J.P, x, y, z, 1.0), v = dot4(J.P + 4, x, y, z, 1.0), w = dot4(J.P + 8, x, y, z, 1.0);
+        const double w_inv_sq = 1 / (w * w);
+        double ru[6], rv[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const double du = dot4(J.Ju + 4 * k, x, y, z, 1.0), dv = dot4(J.Jv + 4 * k, x, y, z, 1.0), dw = dot4(J.Jw + 4 * k, x, y, z, 1.0);
+          ru[k] = (du * w - dw * u) * w_inv_sq;
+          rv[k] = (dv * w - dw * v) * w_inv_sq;
+        }
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b = a; b < 6; b++) { acc[q] += ru[a] * ru[b]; acc[q] += rv[a] * rv[b]; q++; }
+      }
+    }
+    block_sum_lds<21, GN_THREADS>(acc, s_big);
+    if (tid == 0) {
+      double A[36], Ainv[36];
+      int q = 0;
+      for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { A[a * 6 + b] = acc[q]; A[b * 6 + a] = acc[q]; q++; }
+      inverse6(A, Ainv);
+      for (int k = 0; k < 36; k++) res->cov[k] = Ainv[k];
+    }
+    __syncthreads();
+  };
+
+  // The reference computes the covariance at the end of every refineMotionEstimate(); the second call overwrites the
+  // first one's, so the first is only computed here when the second call is going to bail out (too few inliers left
+  // after the reprojection pruning) and leave it standing.
+  auto refine = [&](bool with_cov) {
     __syncthreads();
     if (S.n_inl < ep.min_features) {
       if (tid == 0) S.status = RVO_INSUFFICIENT_INLIERS;
@@ -1331,46 +1382,7 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, E
       __syncthreads();
       if (S.stop) break;
     }
-    // covariance = (M'M)^-1 at the final parameters, motion_estimate.cpp:1319-1329
-    __syncthreads();
-    if (tid == 0) forward_jac_mats(S.est, fx, px, py, S.jac[0]);
-    if (tid == 64) reverse_jac_mats(S.est, fx, px, py, S.jac[1]);
-    __syncthreads();
-    double acc[21];
-#pragma unroll
-    for (int k = 0; k < 21; k++) acc[k] = 0;
-    for (int item = tid; item < 2 * N; item += GN_THREADS) {
-      const int i = item >> 1, dir = item & 1;
-      if (!pb.m_inlier[mb + i]) continue;
-      {
-        const JacMats& J = S.jac[dir];
-        const double* pt = (dir ? pb.m_rxyz : pb.m_xyz) + (mb + i) * 3;
-        const double x = pt[0], y = pt[1], z = pt[2];
-        const double u = dot4(J.P, x, y, z, 1.0), v = dot4(J.P + 4, x, y, z, 1.0), w = dot4(J.P + 8, x, y, z, 1.0);
-        const double w_inv_sq = 1 / (w * w);
-        double ru[6], rv[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-          const double du = dot4(J.Ju + 4 * k, x, y, z, 1.0), dv = dot4(J.Jv + 4 * k, x, y, z, 1.0), dw = dot4(J.Jw + 4 * k, x, y, z, 1.0);
-          ru[k] = (du * w - dw * u) * w_inv_sq;
-          rv[k] = (dv * w - dw * v) * w_inv_sq;
-        }
-        int q = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-          for (int b = a; b < 6; b++) { acc[q] += ru[a] * ru[b]; acc[q] += rv[a] * rv[b]; q++; }
-      }
-    }
-    block_sum_lds<21, GN_THREADS>(acc, s_big);
-    if (tid == 0) {
-      double A[36], Ainv[36];
-      int q = 0;
-      for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { A[a * 6 + b] = acc[q]; A[b * 6 + a] = acc[q]; q++; }
-      inverse6(A, Ainv);
-      for (int k = 0; k < 36; k++) res->cov[k] = Ainv[k];
-    }
-    __syncthreads();
+    if (with_cov) covariance();
   };
 
   // computeReprojectionError(), motion_estimate.cpp:684-720 (K uses fx, fy)
@@ -1400,20 +1412,27 @@ __global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, E
     __syncthreads();
   };
 
-  refine();
+  refine(false);
+  const bool refined1 = S.status == RVO_SUCCESS;  // (uniform: read after refine()'s closing barrier)
   reproj();
   // drop inliers with a high reprojection error, motion_estimate.cpp:203-214
   {
     __syncthreads();
     int fails = 0;
     for (int i = tid; i < N; i += GN_THREADS)
-      if (pb.m_inlier[mb + i] && pb.m_reproj[mb + i] > ep.inlier_max_reprojection_error) { pb.m_inlier[mb + i] = 0; fails++; }
+      if (pb.m_inlier[mb + i] && pb.m_reproj[mb + i] > ep.inlier_max_reprojection_error) fails++;
     double v[1] = {(double)fails};
     block_sum_lds<1, GN_THREADS>(v, s_big);
     if (tid == 0) { S.n_inl -= (int)v[0]; res->num_reprojection_failures = (int)v[0]; }
     __syncthreads();
+    // the second refine will bail out (too few inliers left): the first estimate's covariance, over the inliers it
+    // was estimated from, is what the reference leaves standing
+    if (refined1 && S.n_inl < ep.min_features) covariance();
+    for (int i = tid; i < N; i += GN_THREADS)
+      if (pb.m_inlier[mb + i] && pb.m_reproj[mb + i] > ep.inlier_max_reprojection_error) pb.m_inlier[mb + i] = 0;
+    __syncthreads();
   }
-  refine();
+  refine(true);
   reproj();
   __syncthreads();
   if (tid == 0) {
