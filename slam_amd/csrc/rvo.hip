@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -134,6 +135,19 @@ static void prof_drain(rvo_ctx* c) {
   c->prof_recs.clear();
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a context: contexts of different sizes
+// in one process must never lower it, so the largest request per kernel (and device) wins.
+static hipError_t raise_dyn_lds(const void* func, int device, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> cur;
+  std::lock_guard<std::mutex> lk(mu);
+  int& have = cur[{func, device}];
+  if (bytes <= have) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
+
 #define LAUNCH_ON(c, STREAM, NAME, KERNEL, GRID, BLOCK, SHMEM, ...)                       \
   do {                                                                                    \
     ProfRec pr_;                                                                          \
@@ -256,6 +270,7 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   if (fl.total > 150 * 1024 || g.gw + 2 > 255 || g.gh + 2 > 255 || (g.gw + 2) * (g.gh + 2) > 64 * 256 ||
       ((g.gw + 7) / 4 + 1) * (g.gh + 2) > 16 * 256) {  // phase A of k_fast_grid: <= 16 four-pixel groups per thread
     g_err = "grid cell too large for LDS"; delete c; return RVO_E_UNSUPPORTED; }
+  HIPCHK(raise_dyn_lds(reinterpret_cast<const void*>(k_fast_grid), device, fl.total));
 
   int rc = 0;
   c->ring_bytes = std::max<size_t>(4096, (size_t)std::max(max_frames, max_pairs) * 12 * 8);
