@@ -345,6 +345,9 @@ struct FastLds {  // byte offsets into dynamic LDS, computed on the host (all mu
 // (feature.cpp:5960-6056, non-strict: an equal neighbour suppresses) runs on the LDS score tile; the
 // survivors are compacted in raster order (the order the reference pushes them into the bucket) and
 // one lane replays libstdc++'s nth_element when the bucket exceeds max-keypoints-per-grid.
+// TPC / SPC: tile and score pitch as compile-time constants (0 = take them from L): with the default 80x80 grid every
+// row offset then folds into the 16-bit immediate of the LDS instructions instead of 64-bit multiply-adds.
+template <int TPC, int SPC>
 __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, FastLds L, const int32_t* __restrict__ slots,
                                                    const int32_t* __restrict__ thr) {
   extern __shared__ __align__(16) uint8_t lds[];
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   const int cx0 = (bi % G.gcols) * g.gw, cy0 = (bi / G.gcols) * g.gh;
   const int cw = min(g.gw, G.w - cx0), ch = min(g.gh, G.h - cy0);
   const uint8_t* __restrict__ img = level_img(fb, g, slot, lvl);
-  const int TP = L.tile_pitch, SP = L.score_pitch;
+  const int TP = TPC ? TPC : L.tile_pitch, SP = SPC ? SPC : L.score_pitch;
 
   // ---- stage cell + 4 px halo: 16-byte global loads from the 16-aligned column at or left of cx0-4, stored as dwords
   // into compact LDS rows of TP bytes whose column shl (= 0 when cells start on multiples of 4) is image column

@@ -270,7 +270,8 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   if (fl.total > 150 * 1024 || g.gw + 2 > 255 || g.gh + 2 > 255 || (g.gw + 2) * (g.gh + 2) > 64 * 256 ||
       ((g.gw + 7) / 4 + 1) * (g.gh + 2) > 16 * 256) {  // phase A of k_fast_grid: <= 16 four-pixel groups per thread
     g_err = "grid cell too large for LDS"; delete c; return RVO_E_UNSUPPORTED; }
-  HIPCHK(raise_dyn_lds(reinterpret_cast<const void*>(k_fast_grid), device, fl.total));
+  HIPCHK(raise_dyn_lds(reinterpret_cast<const void*>(k_fast_grid<0, 0>), device, fl.total));
+  HIPCHK(raise_dyn_lds(reinterpret_cast<const void*>(k_fast_grid<88, 84>), device, fl.total));
 
   int rc = 0;
   c->ring_bytes = std::max<size_t>(4096, (size_t)std::max(max_frames, max_pairs) * 12 * 8);
@@ -426,7 +427,10 @@ static int enqueue_pyramid_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* 
 }
 static int enqueue_features_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots, const int32_t* d_thr) {
   const FrameGeom& g = c->g;
-  LAUNCH_ON(c, st, "fast_grid", k_fast_grid, dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
+  if (c->fl.tile_pitch == 88 && c->fl.score_pitch == 84)  // the default 80x80 grid: pitches as compile-time constants
+    LAUNCH_ON(c, st, "fast_grid", (k_fast_grid<88, 84>), dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
+  else
+    LAUNCH_ON(c, st, "fast_grid", (k_fast_grid<0, 0>), dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
   if (st == c->stream) HIPCHK(hipEventRecord(c->ev_mid, st));  // rvo_wait_peer
   LAUNCH_ON(c, st, "build_keypoints", k_build_keypoints, dim3(g.levels, n), dim3(256), 0, c->fb, g, d_slots);
   LAUNCH_ON(c, st, "descriptors", k_descriptors, dim3((g.kp_total * 5 + 255) / 256, n), dim3(256), 0, c->fb, g, d_slots);
