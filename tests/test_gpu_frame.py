@@ -87,3 +87,24 @@ def test_empty_frame(intr640):
         i = ctx.level_info(0, l)
         assert i["num_keypoints"] == 0 and i["num_detected"] == 0
     ctx.close()
+
+
+def test_batch_of_19_frames_matches_oracle_frame_by_frame(scene, intr640):
+    """The frame kernels deal their workgroups XCD-aware in groups of 8 frames (rvo_dev.h:xcd_map) and keep the natural
+    mapping for a tail of fewer than 8: 19 distinct frames in ONE call (two full groups + a tail of 3), permuted slots,
+    every frame compared with the oracle."""
+    from oracle.pyoracle import Oracle
+    from slam_amd.api import Context
+    n = 19
+    frames = [synth.make_pair(900 + i, intr640, scene, invalid_frac=0.05 * (i % 3))[:2] for i in range(n)]
+    gray = np.stack([f[0] for f in frames])
+    depth = np.stack([f[1] for f in frames])
+    slots = np.array([(7 * i + 3) % n for i in range(n)], np.int32)  # a permutation of 0..18
+    thr = np.array([10 + (i % 4) * 10 for i in range(n)], np.int32)
+    ctx = Context(intr640, max_frames=n, max_pairs=1)
+    ctx.prepare_frames(gray, depth, thr, slots)
+    orc = Oracle(intr640)
+    for i in range(n):
+        orc.prepare(0, gray[i], depth[i], int(thr[i]))
+        _compare_frame(ctx, orc, int(slots[i]), 0, 3)
+    ctx.close()
