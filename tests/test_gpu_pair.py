@@ -214,5 +214,14 @@ def test_batches_in_flight_on_two_contexts_are_independent_and_deterministic(sce
         ctxs[k % 2].match_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, slots)
     for k in range(2):
         assert snapshot(ctxs[k]) == alone[k]
+    # the same with rvo_wait_peer before every submit (a batch starts when the other context's FAST stage is done)
+    for k in range(6):
+        dg, dd = batches[(k + 1) % 2]
+        ctxs[k % 2].wait_peer(ctxs[(k + 1) % 2])
+        ctxs[k % 2].match_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, slots)
+    for k in range(2):
+        assert snapshot(ctxs[k]) == alone[(k + 1) % 2]
+    with pytest.raises(Exception):
+        ctxs[0].wait_peer(ctxs[0])  # a context cannot wait for itself
     for c in ctxs:
         c.close()
