@@ -124,7 +124,7 @@ int rvo_sync(rvo_ctx* ctx);
 
 /* Frame::PrepareFrame (rgbdvo/frame.cpp:37-158) incl. the depth conversion of rgbdvo/vo.cpp:83-87 for
  * n frames: gray is n tightly packed W*H u8 images, depth n tightly packed Wd*Hd u16 images
- * (millimetres, 0 = invalid), fast_thr[n] the FAST threshold per frame, slots[n] the destination
+ * (millimetres, 0 = invalid), fast_thr[n] the FAST threshold per frame (0..255, else RVO_E_INVALID), slots[n] the destination
  * frame slots.  Host-buffer form (copies H2D, then runs, then synchronises). */
 int rvo_prepare_frames(rvo_ctx* ctx, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* fast_thr,
                        const int32_t* slots);

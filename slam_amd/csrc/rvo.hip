@@ -450,6 +450,8 @@ int rvo_prepare_frames_dev(rvo_ctx* c, int n, const uint8_t* gray, const uint16_
   if (n == 0) return RVO_OK;
   for (int i = 0; i < n; i++)
     if (slots[i] < 0 || slots[i] >= c->max_frames) { g_err = "rvo_prepare_frames: slot out of range"; return RVO_E_INVALID; }
+  for (int i = 0; i < n; i++)
+    if (thr[i] < 0 || thr[i] > 255) { g_err = "rvo_prepare_frames: FAST threshold outside 0..255"; return RVO_E_INVALID; }
   HIPCHK(hipSetDevice(c->device));
   std::vector<int32_t> args(2 * (size_t)n);
   memcpy(args.data(), slots, n * 4);

@@ -223,5 +223,7 @@ def test_batches_in_flight_on_two_contexts_are_independent_and_deterministic(sce
         assert snapshot(ctxs[k]) == alone[(k + 1) % 2]
     with pytest.raises(Exception):
         ctxs[0].wait_peer(ctxs[0])  # a context cannot wait for itself
+    with pytest.raises(Exception):  # FAST thresholds outside 0..255 are rejected before anything is enqueued
+        ctxs[0].match_frames_dev(batches[0][0].data_ptr(), batches[0][1].data_ptr(), 300, slots)
     for c in ctxs:
         c.close()
