@@ -206,6 +206,9 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   if (prm->feature_window_size != RVO_WIN) { g_err = "feature-window-size must be 9 in this build"; return RVO_E_UNSUPPORTED; }
   if (prm->num_pyramid_levels < 1 || prm->num_pyramid_levels > RVO_MAX_LEVELS) { g_err = "num-pyramid-levels out of range"; return RVO_E_UNSUPPORTED; }
   if (prm->grid_width < 8 || prm->grid_height < 8 || prm->max_keypoints_per_grid < 1) { g_err = "grid options out of range"; return RVO_E_UNSUPPORTED; }
+  if (prm->fast_threshold_min < 0 || prm->fast_threshold_min > prm->fast_threshold_max || prm->fast_threshold_max > 255 ||
+      prm->fast_init_threshold < 0 || prm->fast_init_threshold > 255) {
+    g_err = "FAST thresholds must satisfy 0 <= min <= max <= 255 and 0 <= init <= 255"; return RVO_E_INVALID; }
   if (intr->width > 2047 || intr->height > 2047 || intr->width < 32 || intr->height < 32) { g_err = "image size out of range"; return RVO_E_UNSUPPORTED; }
   if ((intr->width >> (prm->num_pyramid_levels - 1)) < 24 || (intr->height >> (prm->num_pyramid_levels - 1)) < 24) {
     g_err = "coarsest pyramid level smaller than 24 px"; return RVO_E_UNSUPPORTED;
