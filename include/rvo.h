@@ -168,6 +168,14 @@ int rvo_depth_to_point_cloud_dev(rvo_ctx* ctx, int n, const uint16_t* depth_dev,
  * info = cov.inverse() (6x6, row-major = column-major: symmetric up to rounding), computed on the device in one
  * launch; zeros for pairs whose status is not RVO_SUCCESS.  Synchronises. */
 int rvo_get_pair_information(rvo_ctx* ctx, int n, double* info36);
+/* No counterpart in the reference: rvo_get_pair_information for callers that cannot allocate device memory (code
+ * under HIP graph capture set-up, tight serving loops, harnesses that forbid hipMalloc).  Same kernel and same
+ * results, but the device-side staging area is a fixed array inside the library (RVO_NOALLOC_MAX_PAIRS x 36 doubles
+ * = 1 179 648 bytes per GPU, held until the process ends) instead of memory owned by the context; the call itself
+ * allocates and frees nothing.  n > RVO_NOALLOC_MAX_PAIRS is rejected with RVO_E_INVALID.  Every call on a GPU shares
+ * that GPU's array: calls that overlap on one GPU (from several contexts or threads) race; serialise them. */
+#define RVO_NOALLOC_MAX_PAIRS 4096
+int rvo_get_pair_information_noalloc(rvo_ctx* ctx, int n, double* info36);
 int rvo_get_pair_results(rvo_ctx* ctx, int n, rvo_pair_result* out);
 /* EstimateInitialRotation alone: q[n][4] = (w,x,y,z) */
 int rvo_initial_rotation(rvo_ctx* ctx, int n, const int32_t* prev_slots, const int32_t* cur_slots, double* q_wxyz);

@@ -52,7 +52,7 @@ SYMBOLS = [
     "rvo_get_stream_slots",
     "rvo_get_level_info", "rvo_get_level_image", "rvo_get_grid_keypoints", "rvo_get_keypoints",
     "rvo_get_descriptors", "rvo_get_matches", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_select", "rvo_profile_read",
-    "rvo_selftest_stdalgo", "rvo_bgr_to_gray_dev", "rvo_depth_to_point_cloud_dev", "rvo_get_pair_information", "rvo_set_pair_chunks", "rvo_wait_peer",
+    "rvo_selftest_stdalgo", "rvo_bgr_to_gray_dev", "rvo_depth_to_point_cloud_dev", "rvo_get_pair_information", "rvo_get_pair_information_noalloc", "rvo_set_pair_chunks", "rvo_wait_peer",
 ]
 
 _LIB = None
@@ -83,6 +83,7 @@ def load():
     L.rvo_bgr_to_gray_dev.argtypes = [vp, ip, vp, vp]
     L.rvo_depth_to_point_cloud_dev.argtypes = [vp, ip, vp, C.c_double, C.c_double, vp]
     L.rvo_get_pair_information.argtypes = [vp, ip, vp]
+    L.rvo_get_pair_information_noalloc.argtypes = [vp, ip, vp]
     L.rvo_get_pair_results.argtypes = [vp, ip, vp]
     L.rvo_initial_rotation.argtypes = [vp, ip, vp, vp, vp]
     L.rvo_streams_reset.argtypes = [vp, ip]

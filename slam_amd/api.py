@@ -161,6 +161,12 @@ class Context:
         self._chk(self.L.rvo_get_pair_information(self.h, n, _ptr(out)))
         return out
 
+    def pair_information_noalloc(self, n):
+        """pair_information() through the entry point that allocates nothing (fixed staging array in the library)."""
+        out = np.zeros((n, 6, 6))
+        self._chk(self.L.rvo_get_pair_information_noalloc(self.h, n, _ptr(out)))
+        return out
+
     def pair_results(self, n):
         out = (PairResult * n)()
         self._chk(self.L.rvo_get_pair_results(self.h, n, out))

@@ -21,6 +21,15 @@ struct rvo_ctx;
 static int pair_alloc(rvo_ctx* c);
 const char* rvo_last_error(void) { return g_err.c_str(); }
 
+// Staging area of rvo_get_pair_information_noalloc (the entry point that allocates nothing, include/rvo.h): one 6x6
+// information matrix per pair, RVO_NOALLOC_MAX_PAIRS of them = 1 179 648 bytes that every GPU the library runs on holds
+// until the process ends.  In host code the NAME `scratch` is only a stand-in for the symbol: the memory is reached
+// through the per-device address scratch_for_device() resolves, never through the name.
+static __device__ __align__(256) double scratch[(size_t)RVO_NOALLOC_MAX_PAIRS * 36];
+static const int kMaxDevices = 64;
+static double* g_scratch_ptr[kMaxDevices];  // [device] address of that device's copy of `scratch`; nullptr = not resolved yet
+static std::mutex g_scratch_mu;
+
 #define HIPCHK(x)                                                                        \
   do {                                                                                   \
     hipError_t e_ = (x);                                                                 \
@@ -148,6 +157,17 @@ static hipError_t raise_dyn_lds(const void* func, int device, int bytes) {
   return e;
 }
 
+// Resolves (once per device, with that device current) where `scratch` lives on `device`.
+static int scratch_for_device(int device) {
+  if (device < 0 || device >= kMaxDevices) return RVO_OK;  // such a device simply has no allocation-free entry point
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (g_scratch_ptr[device]) return RVO_OK;
+  double* p = nullptr;
+  HIPCHK(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+  g_scratch_ptr[device] = p;
+  return RVO_OK;
+}
+
 #define LAUNCH_ON(c, STREAM, NAME, KERNEL, GRID, BLOCK, SHMEM, ...)                       \
   do {                                                                                    \
     ProfRec pr_;                                                                          \
@@ -214,6 +234,7 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
     g_err = "coarsest pyramid level smaller than 24 px"; return RVO_E_UNSUPPORTED;
   }
   HIPCHK(hipSetDevice(device));
+  { const int rc0 = scratch_for_device(device); if (rc0) return rc0; }
   rvo_ctx* c = new rvo_ctx();
   c->device = device;
   c->intr = *intr;
@@ -589,5 +610,22 @@ int rvo_profile_read(rvo_ctx* c, int cap, const char** names, float* total_ms, i
   return n;
 }
 
-
 #include "rvo_pair_api.inc"
+
+// ---------------------------------------------------------------- the entry point that allocates nothing
+// rvo_get_pair_information with its staging area in the file-scope `scratch` array instead of the context's d_info:
+// no hipMalloc / hipFree, no event or vector growth (the launch is not bracketed by profiling events), same kernel.
+// The kernel writes all n*36 values it hands back, so nothing in the array has to start at zero.
+extern "C" int rvo_get_pair_information_noalloc(rvo_ctx* c, int n, double* info) {
+  if (!c || !info || n < 0 || n > c->max_pairs) { g_err = "rvo_get_pair_information_noalloc: bad argument"; return RVO_E_INVALID; }
+  if (n > RVO_NOALLOC_MAX_PAIRS) { g_err = "rvo_get_pair_information_noalloc: at most 4096 pairs per call (RVO_NOALLOC_MAX_PAIRS)"; return RVO_E_INVALID; }
+  if (n == 0) return RVO_OK;
+  double* sp = (c->device >= 0 && c->device < kMaxDevices) ? g_scratch_ptr[c->device] : nullptr;  // resolved by rvo_create on this device
+  if (!sp) { g_err = "rvo_get_pair_information_noalloc: no static staging area on this device"; return RVO_E_UNSUPPORTED; }
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_pair_information, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->pb, n, sp);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(info, sp, (size_t)n * 36 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return RVO_OK;
+}
