@@ -4,7 +4,8 @@
 Workload (configs[1]): a batch of 256 independent synthetic 640x480 gray+depth frame pairs per GPU, 3-level
 pyramid, default feature grid.  One step = Frame::PrepareFrame on all 512 frames + FrameMatcher::Match on the
 256 pairs (initial rotation, matching, refinement, clique, Gauss-Newton), inputs resident in HBM.
-N > 1: one process per GPU (torchrun), every rank runs its own 256 pairs (weak scaling, no collective in the
+N > 1: one process per GPU -- `python bench.py --gpus N` starts the N ranks itself (slam_amd/launch.py); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the launcher's ranks are used -- every rank runs its own 256 pairs (weak scaling, no collective in the
 timed loop); the per-pair poses are gathered once at the end over RCCL (all_gather) and timed separately.
 
 Prints ONE JSON line on rank 0.
@@ -37,7 +38,8 @@ def make_batch(n_pairs: int, seed0: int):
     from concurrent.futures import ProcessPoolExecutor
     from slam_amd import synth
     synth.make_texture()  # build once before forking
-    workers = int(os.environ.get("RVO_BENCH_WORKERS", "8"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    workers = int(os.environ.get("RVO_BENCH_WORKERS", "8" if world <= 2 else "6"))
     with ProcessPoolExecutor(max_workers=workers) as ex:
         out = list(ex.map(_render_pair, [(seed0 + i,) for i in range(n_pairs)], chunksize=4))
     gray = np.empty((2 * n_pairs, 480, 640), np.uint8)
@@ -81,10 +83,15 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
 
+    # `python bench.py --gpus N` without an outer launcher: start the N rank processes ourselves (one per GPU) and relay
+    # rank 0's JSON line.  Under torch.distributed.run (RANK / WORLD_SIZE already set) this process IS a rank.
+    from slam_amd.launch import launched_by_parent, spawn_ranks
+    if a.gpus > 1 and not launched_by_parent():
+        sys.exit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], a.gpus))
+
     # stdout carries exactly one JSON line: library banners (gloo, RCCL, HIP) that print to fd 1 are sent to stderr
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+    from slam_amd.launch import reserve_stdout
+    json_fd = reserve_stdout()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -195,6 +202,7 @@ def main():
     res = ctx.pair_results(n_pairs)
     gather_ms = None
     gather_backend = None
+    gather_ranks = None
     if world > 1:
         from slam_amd.dist import gather_trajectories
         local = np.stack([np.concatenate([r["pose"].reshape(12), [r["status"], r["num_inliers"]]]) for r in res])
@@ -209,7 +217,10 @@ def main():
             allp = gather_trajectories(local, None)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        assert allp.shape == (world * n_pairs, 14)
+        gather_ranks = dist.get_world_size()
+        assert allp.shape == (gather_ranks * n_pairs, 14)
+        mine = allp[rank * n_pairs:(rank + 1) * n_pairs]
+        assert np.array_equal(mine, local)  # every rank finds its own block where its rank says
 
     ok = sum(r["status"] == 1 for r in res)
     err = max(np.abs(r["pose"] - T_gt[i]).max() for i, r in enumerate(res) if r["status"] == 1) if ok else float("nan")
@@ -320,7 +331,7 @@ def main():
                     kernels_note=f"separate pass of {post_steps} steps after the timed region with HIP events around every launch "
                                  "(that instrumentation costs about 7 %); the timed region brackets only the dominant kernel", stats=stats,
                     check=dict(pairs_success=ok, max_abs_pose_err_vs_truth=float(err)),
-                    gather_ms=gather_ms, gather_backend=gather_backend)
+                    gather_ms=gather_ms, gather_backend=gather_backend, gather_ranks=gather_ranks)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     for c in ctxs:
         c.close()

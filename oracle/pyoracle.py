@@ -202,11 +202,11 @@ class OracleVO:
     def process(self, gray, depth):
         gray = np.ascontiguousarray(gray, np.uint8)
         depth = np.ascontiguousarray(depth, np.uint16)
-        oi = np.zeros(6, np.int32)
+        oi = np.zeros(8, np.int32)
         od = np.zeros(24, np.float64)
         rc = self.o.L.orc_vo_process(self.h, _p(gray), _p(depth), _p(oi), _p(od))
         return dict(rc=int(rc), fast_thr=int(oi[1]), keyframe_changed=bool(oi[2]), status=int(oi[3]),
-                    num_inliers=int(oi[4]), num_matches=int(oi[5]), pose=od[:12].reshape(3, 4).copy(),
+                    num_inliers=int(oi[4]), num_matches=int(oi[5]), used_fallback=bool(oi[6]), pose=od[:12].reshape(3, 4).copy(),
                     curr_to_ref=od[12:].reshape(3, 4).copy())
 
     def close(self):

@@ -1324,6 +1324,7 @@ struct VO {
   Iso pose, ref_to_prev, curr_to_prev, curr_to_ref;
   double curr_to_ref_cov[36];
   bool failed = false;
+  bool used_fallback = false;  // this Process() took its estimate from the retry against the previous frame (vo.cpp:131-151)
   VO(Ctx* ctx, int base_slot) : c(ctx) {
     slot_ref = base_slot; slot_prev = base_slot + 1; slot_curr = base_slot + 2;
     fast_thr = c->prm.fast_init_threshold;
@@ -1341,6 +1342,7 @@ struct VO {
     else std::swap(slot_prev, slot_curr);
     bool ref_changed = ref_changed_flag;
     ref_changed_flag = false;
+    used_fallback = false;
     curr_to_prev.setIdentity();
     Frame* cur = c->slot(slot_curr);
     cur->Prepare(gray, raw_depth, fast_thr);
@@ -1375,6 +1377,7 @@ struct VO {
         pose = iso_mul(pose, curr_to_prev);
         ref_changed_flag = true;
         curr_to_ref = iso_mul(iso_inverse(ref_to_prev), curr_to_prev);
+        used_fallback = true;
       }
     }
     if (c->est.status != SUCCESS) { failed = true; return -1; }  // reference: exit(-1), vo.cpp:154-158
@@ -1544,12 +1547,12 @@ void orc_std_select_or_sort(uint32_t* keys, int n, int shift, int nth) {
 // ---- streaming VO
 void* orc_vo_create(void* cv, int base_slot) { return new VO((Ctx*)cv, base_slot); }
 void orc_vo_destroy(void* v) { delete (VO*)v; }
-// out_i[6] = rc, fast_thr(after), keyframe_changed, status, num_inliers, num_matches ; out_d[24] = pose 3x4, curr_to_ref 3x4
+// out_i[7] = rc, fast_thr(after), keyframe_changed, status, num_inliers, num_matches, used_fallback ; out_d[24] = pose 3x4, curr_to_ref 3x4
 int orc_vo_process(void* vv, const uint8_t* gray, const uint16_t* depth, int32_t* out_i, double* out_d) {
   VO* v = (VO*)vv;
   int rc = v->Process(gray, depth);
   out_i[0] = rc; out_i[1] = v->fast_thr; out_i[2] = v->ref_changed_flag; out_i[3] = v->c->est.status;
-  out_i[4] = v->c->est.num_inliers; out_i[5] = (int)v->c->est.matches.size();
+  out_i[4] = v->c->est.num_inliers; out_i[5] = (int)v->c->est.matches.size(); out_i[6] = v->used_fallback;
   iso_to_3x4(v->pose, out_d);
   iso_to_3x4(v->curr_to_ref, out_d + 12);
   return rc;

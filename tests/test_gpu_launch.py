@@ -1,0 +1,27 @@
+"""GPU: `python bench.py --gpus 2` as the driver starts it (no outer torchrun) runs two ranks and prints ONE line with
+n_gpus == 2.  On the one-GPU box both ranks share the card, so the trajectory gather reports its gloo fallback; on a
+node with two GPUs it is RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["RVO_BENCH_WORKERS"] = "4"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--pairs", "32", "--no-cpu"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["gather_ranks"] == 2 and d["scaling"] == "weak"
+    assert d["gather_backend"] is not None and d["gather_ms"] is not None
+    assert d["value"] > 0 and d["check"]["pairs_success"] == 32
+    assert d["cpu_baseline"] is None  # only timed at N = 1

@@ -4,6 +4,7 @@ collective in the loop; at the end ONE gather of the trajectories (RCCL, gloo fa
 the pose graph's vertex file format (slam_amd/vertex_io.py) and prints one JSON line.
 
   python tools/run_streams.py --streams 64 --frames 12
+  python tools/run_streams.py --gpus 8 --streams 4096 --frames 300      (starts its own 8 ranks, slam_amd/launch.py)
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/run_streams.py --streams 4096 --frames 300
 """
 import argparse, json, os, sys, time
@@ -25,7 +26,11 @@ def main():
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--out", default="")
+    ap.add_argument("--gpus", type=int, default=1, help="started without torchrun: launch this many rank processes (one per GPU)")
     a = ap.parse_args()
+    from slam_amd.launch import launched_by_parent, spawn_ranks
+    if a.gpus > 1 and not launched_by_parent():
+        sys.exit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], a.gpus))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     from concurrent.futures import ProcessPoolExecutor
@@ -99,7 +104,7 @@ def main():
         ok = int((allt[:, 1:, 12] == 1).sum())
         print(json.dumps(dict(streams=a.streams, frames=a.frames, n_gpus=world, stream_frames_per_s=a.streams * a.frames / dt,
                               estimates_ok=ok, estimates=a.streams * (a.frames - 1), max_abs_pose_err_vs_truth=err,
-                              gather_backend=backend)))
+                              gather_backend=backend, gather_ranks=world if world > 1 else None)))
     for c in ctxs:
         c.close()
     if world > 1:
