@@ -58,6 +58,34 @@ SYMBOLS = [
 _LIB = None
 
 
+def _share_one_hip_runtime():
+    """A process must hold ONE copy of the HIP/HSA runtime.  librgbdvo_hip.so needs `libamdhip64.so.7` and would take
+    /opt/rocm's; the PyTorch wheel bundles its own copy as torch/lib/libamdhip64.so (same soname) and asks for it by
+    file name, so when this library is loaded BEFORE torch the process ends up with two runtimes and the second one to
+    initialise finds no device (torch then reports "No HIP GPUs are available"; seen in round 1 and first blamed on
+    rvo_destroy).  In the other order the dynamic linker binds this library to torch's copy by soname.  So: if no HIP
+    runtime is mapped yet and a torch installation with a bundled runtime exists, map that copy first (without
+    importing torch).  RVO_HIP_RUNTIME=system skips this (processes that never load torch lose nothing either way)."""
+    if os.environ.get("RVO_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return
+    except OSError:
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for d in (spec.submodule_search_locations or []) if spec else []:
+        p = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+            return
+
+
 def load():
     """Load the HIP library.  Raises (no fallback) if it has not been built."""
     global _LIB
@@ -65,6 +93,7 @@ def load():
         return _LIB
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run ./build.sh (python -c 'import __graft_entry__ as g; g.build()')")
+    _share_one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.rvo_last_error.restype = C.c_char_p
     vp, ip = C.c_void_p, C.c_int

@@ -22,15 +22,3 @@ def scene():
 def intr640():
     from slam_amd import synth
     return synth.default_intrinsics(640, 480)
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _torch_owns_the_gpu_first(request):
-    """Some GPU tests hold device buffers in torch tensors.  torch's lazy HIP initialisation has been seen to report
-    "No HIP GPUs are available" when it first runs after the library's own contexts came and went in the same process,
-    so initialise it once, before any test, whenever a GPU run is requested.  Nothing happens on the CPU-only tier."""
-    if any(item.get_closest_marker("gpu") for item in request.session.items):
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    yield

@@ -25,3 +25,16 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert d["gather_backend"] is not None and d["gather_ms"] is not None
     assert d["value"] > 0 and d["check"]["pairs_success"] == 32
     assert d["cpu_baseline"] is None  # only timed at N = 1
+
+
+def test_library_before_torch_in_one_process():
+    """rvo_create / compute / rvo_destroy BEFORE torch.cuda.init(), then torch, then the library again, in a fresh process
+    (no fixture initialises torch first any more).  Round 1 hid this order behind a conftest fixture; the cause was two
+    copies of the HIP runtime in the process (slam_amd/_lib.py:_share_one_hip_runtime)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "order_probe.py")], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = out.stdout.splitlines()
+    assert "avail True" in lines and "45" in lines and "ok" in lines, out.stdout
+    maps_line = [l for l in out.stdout.splitlines() if l.startswith("hip runtimes mapped:")]
+    assert maps_line and maps_line[0].split(":")[1].split()[0] == "1", out.stdout
