@@ -74,6 +74,9 @@ class FrameMatcher {
     const int n = (int)target_ids.size();
     edges->assign(n, LoopClosureEdge());
     if (n == 0) return 0;
+    if (ref_id < 0 || ref_id >= max_keyframes_) { fprintf(stderr, "FrameMatcher: keyframe id %d out of range\n", ref_id); return 0; }
+    for (int i = 0; i < n; i++)  // ids map to slots 2 + id: -1 / -2 would name the live target / reference frame
+      if (target_ids[i] < 0 || target_ids[i] >= max_keyframes_) { fprintf(stderr, "FrameMatcher: keyframe id %d out of range\n", target_ids[i]); return 0; }
     std::vector<int32_t> ref(n, 2 + ref_id), tgt(n);
     for (int i = 0; i < n; i++) tgt[i] = 2 + target_ids[i];
     std::vector<rvo_pair_result> r(n);

@@ -86,7 +86,7 @@ class MotionEstimator {
   MotionEstimateStatusCode status_ = NO_DATA;
   int32_t num_matches_ = 0, num_inliers_ = 0, num_fail_ = 0;
   double mean_err_ = 0;
-  Eigen::Isometry3d motion_;
+  Eigen::Isometry3d motion_ = Eigen::Isometry3d::Identity();
   Eigen::MatrixXd cov_;
   mutable bool loaded_ = false;
   mutable std::vector<FeatureMatch> matches_;

@@ -34,7 +34,8 @@ class RGBDVO {
     rvo_stream_result r;
     if (rvo_stream_step(ctx_, 1, gray, raw_depth, &r)) { fprintf(stderr, "RGBDVO: %s\n", rvo_last_error()); exit(-1); }
     if (r.rc == 0) return;
-    pose_ = compose(init_pose_, detail::iso_from_3x4(r.pose));
+    integrated_ = detail::iso_from_3x4(r.pose);
+    pose_ = compose(init_pose_, integrated_);
     curr_to_ref_ = detail::iso_from_3x4(r.curr_to_ref);
     cov_ = detail::mat6_from(r.cov);
     keyframe_changed_ = r.keyframe_changed != 0;
@@ -55,17 +56,26 @@ class RGBDVO {
   const Eigen::MatrixXd& GetCurrToRefCov() const { return cov_; }
   bool IsKeyFrameChanged() const { return keyframe_changed_; }
   const MotionEstimator* GetMotionEstimator() const { return &est_; }
-  // The engine integrates from identity; an initial pose is applied on the left (pose_ = init * integrated),
-  // which equals the reference's pose_ = pose_ * curr_to_prev chain started from `pose` (vo.hpp:42-45).
-  const void SetInitPose(Eigen::Isometry3d pose = Eigen::Isometry3d::Identity()) { init_pose_ = pose; pose_ = pose; }
+  // vo.hpp:42-45: pose_ = pose, at any time.  The engine integrates from identity (`integrated_`), the facade keeps
+  // pose_ = init_pose_ * integrated_; setting init_pose_ = pose * integrated_^-1 makes GetPose() equal `pose` now and
+  // continue the reference's pose_ = pose_ * curr_to_prev chain from there, also when called in the middle of a run.
+  const void SetInitPose(Eigen::Isometry3d pose = Eigen::Isometry3d::Identity()) {
+    init_pose_ = compose(pose, rigid_inverse(integrated_));
+    pose_ = pose;
+  }
 
  private:
   RGBDVO(const Camera& camera, const Options& options) : camera_(camera.MakeCopy()) {
     rvo_default_vo_params(&prm_);
     detail::params_from_options(options, &prm_);
     const rvo_intrinsics in = camera_->GetInputCameraParameters().toC();
-    if (rvo_create(&in, &prm_, 0, 3, 1, &ctx_) || rvo_streams_reset(ctx_, 1)) { fprintf(stderr, "RGBDVO: %s\n", rvo_last_error()); abort(); }
+    int device = 0;  // the reference has no notion of a device; RVO_DEVICE selects the GPU of the singleton
+    if (const char* e = getenv("RVO_DEVICE")) device = atoi(e);
+    if (rvo_create(&in, &prm_, device, 3, 1, &ctx_) || rvo_streams_reset(ctx_, 1)) { fprintf(stderr, "RGBDVO: %s\n", rvo_last_error()); abort(); }
     cov_ = Eigen::MatrixXd(6, 6);
+    // the reference leaves pose_ uninitialised until SetInitPose (vo.hpp:42-45): Identity here
+    pose_ = Eigen::Isometry3d::Identity(); init_pose_ = Eigen::Isometry3d::Identity();
+    integrated_ = Eigen::Isometry3d::Identity(); curr_to_ref_ = Eigen::Isometry3d::Identity();
   }
   ~RGBDVO() { rvo_destroy(ctx_); }
   static RGBDVO*& inst() { static RGBDVO* p = nullptr; return p; }
@@ -80,12 +90,22 @@ class RGBDVO {
     return r;
   }
 
+  static Eigen::Isometry3d rigid_inverse(const Eigen::Isometry3d& a) {  // [R t]^-1 = [R' -R't]
+    Eigen::Isometry3d r = Eigen::Isometry3d::Identity();
+    for (int i = 0; i < 3; i++) {
+      double s = 0;
+      for (int j = 0; j < 3; j++) { r.matrix()(i, j) = a.matrix()(j, i); s += a.matrix()(j, i) * a.matrix()(j, 3); }
+      r.matrix()(i, 3) = -s;
+    }
+    return r;
+  }
+
   std::unique_ptr<Camera> camera_;
   rvo_params prm_;
   rvo_ctx* ctx_ = nullptr;
   size_t init_cnt_ = 0;
   bool keyframe_changed_ = false;
-  Eigen::Isometry3d pose_, init_pose_, curr_to_ref_;
+  Eigen::Isometry3d pose_, init_pose_, integrated_, curr_to_ref_;
   Eigen::MatrixXd cov_;
   MotionEstimator est_;
 };

@@ -610,6 +610,10 @@ struct Frame {  // frame.cpp
             k.rect_base_uv[1] >= height)
           continue;
         int32_t du = (int32_t)(k.rect_base_uv[0] + 0.5), dv = (int32_t)(k.rect_base_uv[1] + 0.5);
+        // rect_u in [W-0.5, W) gives du = W (distorted cameras): depth index and ray index (depth.cpp:72, v*W+u) then name
+        // column 0 of the next row, which is what the reference reads; past the last row both leave their buffers
+        // (undefined in the reference, Eigen's assert aborts there) -- documented deviation: the keypoint is dropped.
+        if (depth.RGB2DepthIdx(du, dv) >= depth.dw * depth.dh || dv * width + du >= width * height) continue;
         if (!depth.HaveXYZ(du, dv)) continue;
         k.xyzw[0] = k.xyzw[1] = k.xyzw[2] = k.xyzw[3] = NAN;
         k.has_depth = false;
@@ -635,8 +639,9 @@ struct Frame {  // frame.cpp
           k.xyz[0] = k.xyz[1] = k.xyz[2] = NAN;
         } else {
           k.has_depth = true;
-          double rx = u * depth.fx_inv + depth.neg_cx_div_fx;  // depth.cpp:32-34 rays
-          double ry = v * depth.fy_inv + depth.neg_cy_div_fy;
+          const int32_t ri = v * width + u;  // rays_->col(v * rgb_width_ + u), depth.cpp:72
+          double rx = (ri % width) * depth.fx_inv + depth.neg_cx_div_fx;  // depth.cpp:32-34 rays
+          double ry = (ri / width) * depth.fy_inv + depth.neg_cy_div_fy;
           double zd = z;
           k.xyz[0] = zd * rx; k.xyz[1] = zd * ry; k.xyz[2] = zd * 1.0;
           k.xyzw[0] = k.xyz[0]; k.xyzw[1] = k.xyz[1]; k.xyzw[2] = k.xyz[2]; k.xyzw[3] = 1;

@@ -314,6 +314,9 @@ class FrameMatcher:
 
     def MatchCachedKeyFrames(self, ref_id: int, target_ids):
         """[(target_id, valid, motion 4x4, cov 6x6, information 6x6)] for every candidate, in one batch."""
+        for i in [ref_id, *target_ids]:  # ids map to slots 2 + id; -1 / -2 would name the live target / reference frame
+            if not 0 <= int(i) < self.max_keyframes:
+                raise RvoError(f"keyframe id {i} out of range")
         t = [2 + int(i) for i in target_ids]
         res = self.ctx.match_pairs([2 + ref_id] * len(t), t)
         info = self.ctx.pair_information(len(t))

@@ -750,12 +750,17 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
             const int du = (int)((double)ru + 0.5), dv = (int)((double)rv + 0.5);
             // Depth::RGB2DepthIdx, depth.hpp:41-43
             const int di = (int)((double)dv * (double)g.ys) * g.Wd + (int)((double)du * (double)g.xs);
-            const uint16_t d = depth[di];
+            // rect_u in [W-0.5, W) rounds to du = W (distorted cameras only): the reference then reads the depth pixel
+            // and the ray (rays_->col(v*W+u), depth.cpp:72) of column 0 of the NEXT row; past the last row both reads
+            // leave their buffers (undefined there: Eigen's assert aborts) -- such a keypoint is dropped here.
+            const int ri = dv * g.W + du;
+            const uint16_t d = (di < g.Wd * g.Hd && ri < g.W * g.H) ? depth[di] : (uint16_t)0;
             if (d) {  // HaveXYZ: d ? d*1e-3 : NaN
               flag = 1;
               const double z = (double)(float)((double)d * 1e-3);
-              const double rx = (double)du * g.fx_inv + g.neg_cx_div_fx;
-              const double ry = (double)dv * g.fy_inv + g.neg_cy_div_fy;
+              const int rxu = du < g.W ? du : du - g.W, ryv = du < g.W ? dv : dv + 1;  // pixel the ray index ri names
+              const double rx = (double)rxu * g.fx_inv + g.neg_cx_div_fx;
+              const double ry = (double)ryv * g.fy_inv + g.neg_cy_div_fy;
               X = z * rx; Y = z * ry; Z = z;
             }
           }

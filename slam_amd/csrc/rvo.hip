@@ -57,6 +57,7 @@ struct rvo_ctx {
   int max_frames = 0, max_pairs = 0;
   std::vector<void*> allocs;
   std::vector<float> xmap, ymap;
+  std::vector<uint8_t> seen;  // check_slots scratch
   int32_t* d_fargs = nullptr;  // [2*max_frames] slots, thr
   uint8_t* d_gray_stage = nullptr;
   uint16_t* d_depth_stage = nullptr;
@@ -221,14 +222,23 @@ static void make_xy_map(const rvo_intrinsics& in, std::vector<float>& X, std::ve
     }
 }
 
+// Everything rvo_create does once the context object exists; on any failure the caller destroys the half-built context
+// (rvo_destroy copes with members that were never created), so no path leaks streams, events, pinned or device memory.
+static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* prm, int device, int max_frames, int max_pairs);
+
 int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, int max_frames, int max_pairs, rvo_ctx** out) {
   if (!intr || !prm || !out || max_frames < 1 || max_pairs < 0) { g_err = "rvo_create: bad argument"; return RVO_E_INVALID; }
+  *out = nullptr;
   if (prm->feature_window_size != RVO_WIN) { g_err = "feature-window-size must be 9 in this build"; return RVO_E_UNSUPPORTED; }
   if (prm->num_pyramid_levels < 1 || prm->num_pyramid_levels > RVO_MAX_LEVELS) { g_err = "num-pyramid-levels out of range"; return RVO_E_UNSUPPORTED; }
   if (prm->grid_width < 8 || prm->grid_height < 8 || prm->max_keypoints_per_grid < 1) { g_err = "grid options out of range"; return RVO_E_UNSUPPORTED; }
   if (prm->fast_threshold_min < 0 || prm->fast_threshold_min > prm->fast_threshold_max || prm->fast_threshold_max > 255 ||
       prm->fast_init_threshold < 0 || prm->fast_init_threshold > 255) {
     g_err = "FAST thresholds must satisfy 0 <= min <= max <= 255 and 0 <= init <= 255"; return RVO_E_INVALID; }
+  if (prm->target_pixels_per_feature < 1) { g_err = "target-pixels-per-feature must be positive"; return RVO_E_INVALID; }  // vo.cpp:42-43 divides by it
+  if (intr->depth_width < 1 || intr->depth_height < 1) { g_err = "depth image size must be positive"; return RVO_E_INVALID; }
+  if (!(std::isfinite(intr->fx) && std::isfinite(intr->fy) && intr->fx != 0.0 && intr->fy != 0.0 && std::isfinite(intr->cx) && std::isfinite(intr->cy))) {
+    g_err = "fx, fy must be finite and non-zero, cx, cy finite"; return RVO_E_INVALID; }
   if (intr->width > 2047 || intr->height > 2047 || intr->width < 32 || intr->height < 32) { g_err = "image size out of range"; return RVO_E_UNSUPPORTED; }
   if ((intr->width >> (prm->num_pyramid_levels - 1)) < 24 || (intr->height >> (prm->num_pyramid_levels - 1)) < 24) {
     g_err = "coarsest pyramid level smaller than 24 px"; return RVO_E_UNSUPPORTED;
@@ -236,6 +246,13 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   HIPCHK(hipSetDevice(device));
   { const int rc0 = scratch_for_device(device); if (rc0) return rc0; }
   rvo_ctx* c = new rvo_ctx();
+  const int rc = ctx_init(c, intr, prm, device, max_frames, max_pairs);
+  if (rc) { rvo_destroy(c); return rc; }
+  *out = c;
+  return RVO_OK;
+}
+
+static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* prm, int device, int max_frames, int max_pairs) {
   c->device = device;
   c->intr = *intr;
   c->prm = *prm;
@@ -267,7 +284,7 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
     L.kp_off = koff; koff += L.kp_cap;
   }
   g.img_bytes = img_off; g.total_buckets = boff; g.kp_total = koff;
-  if (koff > 65535) { g_err = "more than 65535 keypoint slots per frame"; delete c; return RVO_E_UNSUPPORTED; }
+  if (koff > 65535) { g_err = "more than 65535 keypoint slots per frame"; return RVO_E_UNSUPPORTED; }
   c->cam = CamParams{intr->fx, intr->fy, intr->cx, intr->cy, intr->fx};
   c->ep = EstParams{prm->inlier_max_reprojection_error, prm->clique_inlier_threshold, prm->max_mean_reprojection_error,
                     prm->feature_search_window, prm->min_features_for_estimate, 0.0};
@@ -293,7 +310,7 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   fl.total = fl.off_misc + 64 + round_up((g.gw * g.gh + 31) / 32 * 4, 16);
   if (fl.total > 150 * 1024 || g.gw + 2 > 255 || g.gh + 2 > 255 || (g.gw + 2) * (g.gh + 2) > 64 * 256 ||
       ((g.gw + 7) / 4 + 1) * (g.gh + 2) > 16 * 256) {  // phase A of k_fast_grid: <= 16 four-pixel groups per thread
-    g_err = "grid cell too large for LDS"; delete c; return RVO_E_UNSUPPORTED; }
+    g_err = "grid cell too large for LDS"; return RVO_E_UNSUPPORTED; }
   HIPCHK(raise_dyn_lds(reinterpret_cast<const void*>(k_fast_grid<0, 0>), device, fl.total));
   HIPCHK(raise_dyn_lds(reinterpret_cast<const void*>(k_fast_grid<88, 84>), device, fl.total));
 
@@ -337,7 +354,7 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   rc |= dalloc(c, &dx, (size_t)g.W * g.H + g.W + 2);  // +1 row: BilinearLookup reads ra+W+1 (camera.hpp:103-109)
   rc |= dalloc(c, &dy, (size_t)g.W * g.H + g.W + 2);
   rc |= dalloc(c, &c->d_fargs, 2 * F);
-  if (rc) { rvo_destroy(c); return RVO_E_NOMEM; }
+  if (rc) return RVO_E_NOMEM;
   HIPCHK(hipMemset(fb.img, 0, F * g.img_bytes));  // PyramidLevel ctor memset, pyramid.cpp:121
   {
     std::vector<const uint16_t*> tab(F);
@@ -358,9 +375,8 @@ int rvo_create(const rvo_intrinsics* intr, const rvo_params* prm, int device, in
   fb.xmap = dx; fb.ymap = dy;
 
   rc = pair_alloc(c);
-  if (rc) { rvo_destroy(c); return rc; }
+  if (rc) return rc;
   HIPCHK(hipDeviceSynchronize());
-  *out = c;
   return RVO_OK;
 }
 
@@ -469,11 +485,21 @@ static int enqueue_prepare(rvo_ctx* c, int n, const int32_t* d_slots, const int3
   return enqueue_prepare_on(c, c->stream, n, d_slots, d_thr);
 }
 
+// Slots of one batch must be distinct: every slot is written by its own workgroups, two frames in one slot would race.
+static int check_slots(rvo_ctx* c, int n, const int32_t* slots, const char* who) {
+  c->seen.assign((size_t)c->max_frames, 0);
+  for (int i = 0; i < n; i++) {
+    if (slots[i] < 0 || slots[i] >= c->max_frames) { g_err = std::string(who) + ": slot out of range"; return RVO_E_INVALID; }
+    if (c->seen[slots[i]]) { g_err = std::string(who) + ": the same slot twice in one batch"; return RVO_E_INVALID; }
+    c->seen[slots[i]] = 1;
+  }
+  return RVO_OK;
+}
+
 int rvo_prepare_frames_dev(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* thr, const int32_t* slots) {
   if (!c || !gray || !depth || !thr || !slots || n < 0 || n > c->max_frames) { g_err = "rvo_prepare_frames: bad argument"; return RVO_E_INVALID; }
   if (n == 0) return RVO_OK;
-  for (int i = 0; i < n; i++)
-    if (slots[i] < 0 || slots[i] >= c->max_frames) { g_err = "rvo_prepare_frames: slot out of range"; return RVO_E_INVALID; }
+  { const int rc0 = check_slots(c, n, slots, "rvo_prepare_frames"); if (rc0) return rc0; }
   for (int i = 0; i < n; i++)
     if (thr[i] < 0 || thr[i] > 255) { g_err = "rvo_prepare_frames: FAST threshold outside 0..255"; return RVO_E_INVALID; }
   HIPCHK(hipSetDevice(c->device));

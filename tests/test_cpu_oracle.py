@@ -208,3 +208,34 @@ def test_front_of_path_conversions_known_answers():
     assert c[0, 1, 2] == z and c[0, 1, 0] == np.float32((1 / 2 - 0.5) * float(z) * 1.2)
     assert c[0, 1, 1] == np.float32((0.5 - 0 / 2) * float(z) * 0.9)
     assert c[0, 0, 2] == 0 and np.signbit(c[0, 0, 0])  # (0/W - 0.5) * 0 = -0.0, kept
+
+
+def test_rvo_create_rejects_bad_arguments_before_touching_the_gpu():
+    """Nothing may throw, divide by zero or exit across the C ABI (include/rvo.h): bad options come back as error codes."""
+    import ctypes as C
+    from slam_amd import _lib, synth
+    from slam_amd.api import default_params
+    L = _lib.load()
+
+    def create(intr_over=None, **prm_over):
+        intr = synth.default_intrinsics(640, 480)
+        intr.update(intr_over or {})
+        i = _lib.Intrinsics(**{k: intr[k] for k, _ in _lib.Intrinsics._fields_})
+        p = default_params(**prm_over)
+        h = C.c_void_p()
+        rc = L.rvo_create(C.byref(i), C.byref(p), 0, 3, 1, C.byref(h))
+        assert h.value is None
+        return rc, L.rvo_last_error().decode()
+
+    assert create(target_pixels_per_feature=0)[0] == -1          # vo.cpp:42-43 divides by it
+    assert create(dict(depth_width=0))[0] == -1
+    assert create(dict(depth_height=-3))[0] == -1
+    assert create(dict(fx=0.0))[0] == -1
+    assert create(dict(fy=float("nan")))[0] == -1
+    assert create(fast_threshold_min=80)[0] == -1               # min > max
+    assert create(fast_init_threshold=300)[0] == -1
+    assert create(feature_window_size=11)[0] == -2              # RVO_E_UNSUPPORTED
+    assert create(num_pyramid_levels=9)[0] == -2
+    assert create(dict(width=4000))[0] == -2
+    rc, msg = create(grid_width=2)
+    assert rc == -2 and msg

@@ -63,6 +63,20 @@ def test_cpp_facade_matches_python_mirror(scene, tmp_path):
     one = FrameMatcher(intr)
     one.SetRefFrame(seq[N - 1][0], seq[N - 1][1])
     from oracle import pyoracle
+    # every candidate edge against the ORACLE's FrameMatcher::Match of the same two frames (pose_graph.cpp:104,132)
+    orc = pyoracle.Oracle(intr, pyoracle.default_params(frame_matcher=True))
+    orc.prepare(0, seq[N - 1][0], seq[N - 1][1], lc.thr)
+    n_valid = 0
+    for tid, valid, motion, cov, info in edges:
+        orc.prepare(1, seq[tid][0], seq[tid][1], lc.thr)
+        ro = orc.match_pair(0, 1)
+        assert valid == (ro["status"] == 1), tid
+        assert np.abs(motion[:3] - ro["pose"]).max() < 1e-9, tid
+        if valid:
+            n_valid += 1
+            np.testing.assert_allclose(cov, ro["cov"], rtol=1e-6, atol=1e-12)
+            np.testing.assert_allclose(info, pyoracle.information(ro["cov"]), rtol=1e-5)
+    assert n_valid >= 3
     for l, (tid, valid, motion, cov, info) in zip(lce, edges):
         assert int(l[1]) == tid and int(l[2]) == int(valid)
         assert np.array_equal(np.array(l[4:16], float).reshape(3, 4), motion[:3])

@@ -108,3 +108,45 @@ def test_batch_of_19_frames_matches_oracle_frame_by_frame(scene, intr640):
         orc.prepare(0, gray[i], depth[i], int(thr[i]))
         _compare_frame(ctx, orc, int(slots[i]), 0, 3)
     ctx.close()
+
+
+def test_distorted_camera_keypoints_that_round_onto_the_image_edge():
+    """Barrel distortion (k1 < 0) maps some pixels to rect_u in [W-0.5, W) / rect_v in [H-0.5, H): (int)(x+0.5) is then W
+    or H.  du = W names column 0 of the next row for the depth pixel and the ray (depth.hpp:41-43, depth.cpp:72): kept,
+    bit-equal to the oracle.  Past the last row the reference reads outside its buffers (undefined): such keypoints are
+    dropped on both sides (deviations).  Dense noise puts a corner candidate on almost every pixel."""
+    from oracle.pyoracle import Oracle, default_params as odef
+    from slam_amd.api import Context, default_params
+    W, H = 320, 240
+    intr = synth.default_intrinsics(W, H)
+    intr["k1"] = -0.1
+    kw = dict(num_pyramid_levels=2, max_keypoints_per_grid=60)
+    ctx = Context(intr, default_params(**kw), max_frames=1, max_pairs=1)
+    orc = Oracle(intr, odef(**kw))
+    assert np.array_equal(ctx.lut()[0], orc.lut()[0]) and np.array_equal(ctx.lut()[1], orc.lut()[1])
+    on_edge = 0
+    for seed in range(4):
+        rng = np.random.default_rng(seed)
+        g = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        d = rng.integers(500, 4000, (H, W)).astype(np.uint16)
+        ctx.prepare_frames(g[None], d[None], 20, [0])
+        orc.prepare(0, g, d, 20)
+        _compare_frame(ctx, orc, 0, 0, 2)
+        for l in range(2):
+            rect = orc.keypoints(0, l)[1]
+            on_edge += int(((rect[:, 0] >= W - 0.5) | (rect[:, 1] >= H - 0.5)).sum())
+    assert on_edge > 0, "no keypoint exercised the edge rounding"
+    ctx.close()
+
+
+def test_duplicate_slots_in_one_batch_are_rejected(intr640):
+    from slam_amd.api import Context, RvoError
+    ctx = Context(intr640, max_frames=4, max_pairs=2)
+    g = np.zeros((2, 480, 640), np.uint8)
+    d = np.zeros((2, 480, 640), np.uint16)
+    with pytest.raises(RvoError, match="twice"):
+        ctx.prepare_frames(g, d, 20, [1, 1])
+    with pytest.raises(RvoError, match="range"):
+        ctx.prepare_frames(g, d, 20, [1, 4])
+    ctx.prepare_frames(g, d, 20, [1, 3])
+    ctx.close()
