@@ -203,20 +203,17 @@ def main():
     gather_ms = None
     gather_backend = None
     gather_ranks = None
+    gather_total_ms = None
     if world > 1:
-        from slam_amd.dist import gather_trajectories
+        from slam_amd.dist import gather_trajectories_auto
         local = np.stack([np.concatenate([r["pose"].reshape(12), [r["status"], r["num_inliers"]]]) for r in res])
         torch.cuda.synchronize()
         barrier()
         g0 = time.perf_counter()
-        try:
-            allp = gather_trajectories(local, dev)
-            gather_backend = "nccl"
-        except Exception as e:  # e.g. ranks sharing one GPU in a rehearsal: RCCL refuses duplicate devices
-            gather_backend = f"gloo (nccl gather failed: {type(e).__name__})"
-            allp = gather_trajectories(local, None)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        # RCCL through the C ABI (rvo_gather_trajectories) -> torch's nccl -> gloo, agreed between the ranks
+        allp, gather_backend, gather_t = gather_trajectories_auto(local, dev_index)
+        gather_ms = gather_t.get("gather_ms")
+        gather_total_ms = (time.perf_counter() - g0) * 1e3  # incl. communicator set-up and transports that were refused
         gather_ranks = dist.get_world_size()
         assert allp.shape == (gather_ranks * n_pairs, 14)
         mine = allp[rank * n_pairs:(rank + 1) * n_pairs]
@@ -331,8 +328,12 @@ def main():
                     kernels_note=f"separate pass of {post_steps} steps after the timed region with HIP events around every launch "
                                  "(that instrumentation costs about 7 %); the timed region brackets only the dominant kernel", stats=stats,
                     check=dict(pairs_success=ok, max_abs_pose_err_vs_truth=float(err)),
-                    gather_ms=gather_ms, gather_backend=gather_backend, gather_ranks=gather_ranks)
+                    gather_ms=gather_ms, gather_total_ms=gather_total_ms, gather_backend=gather_backend, gather_ranks=gather_ranks)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if world > 1:
+        from slam_amd import dist as rdist
+        if rdist.HUNG:  # a collective attempt timed out: its helper thread still blocks inside RCCL, the line is out
+            os._exit(0)
     for c in ctxs:
         c.close()
     if world > 1:

@@ -18,6 +18,7 @@
 #ifndef RVO_H_
 #define RVO_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -191,6 +192,32 @@ int rvo_get_stream_results(rvo_ctx* ctx, int n_streams, rvo_stream_result* out);
 int rvo_get_stream_slots(rvo_ctx* ctx, int stream, int32_t* out);
 /* Device pointer to the stream-result array (for a device-side trajectory buffer / RCCL gather). */
 int rvo_stream_results_dev(rvo_ctx* ctx, void** dev_ptr);
+
+/* Device-side trajectories (no counterpart in the reference, whose caller reads GetPose() after every frame,
+ * hand_held_demo.cpp:252): after rvo_streams_record(ctx, max_steps) every rvo_stream_step[_dev] also appends one row of
+ * RVO_TRAJ_DOUBLES doubles per stream -- pose 3x4 row-major, status, num_inliers, rc, used_fallback -- to a device
+ * buffer laid out [stream][max_steps][RVO_TRAJ_DOUBLES], so a run of many steps needs no host read-back (and no
+ * synchronisation) until its end.  Steps beyond max_steps are not recorded.  rvo_streams_reset restarts at row 0. */
+#define RVO_TRAJ_DOUBLES 16
+int rvo_streams_record(rvo_ctx* ctx, int max_steps);
+int rvo_trajectories_dev(rvo_ctx* ctx, void** dev_ptr, int32_t* steps_recorded, int32_t* max_steps);
+/* out[n_streams][steps][RVO_TRAJ_DOUBLES]; synchronises */
+int rvo_get_trajectories(rvo_ctx* ctx, int n_streams, int steps, double* out);
+
+/* ---- multi-GPU: the final trajectory gather.  No counterpart in the reference (one process,
+ * rgbdvo/vo.cpp:55).  Streams are sharded over one process per GPU with no collective in the loop; at the end every
+ * rank contributes one equal-sized device block and receives all of them, rank-major: ncclAllGather over RCCL / xGMI.
+ * Rank 0 calls rvo_comm_get_unique_id and hands the RVO_COMM_ID_BYTES bytes to every rank by whatever channel the host
+ * program has (MPI, a file, torch.distributed's store ...); all ranks then call rvo_comm_create (collective: returns
+ * when every rank has joined).  librccl is opened with dlopen on first use; a world of one needs no RCCL at all.
+ * rvo_gather_trajectories is collective, enqueues on the communicator's own stream and synchronises it; local_dev must
+ * be complete before the call (rvo_sync the producing context first). */
+typedef struct rvo_comm rvo_comm;
+#define RVO_COMM_ID_BYTES 128
+int rvo_comm_get_unique_id(uint8_t* id /* [RVO_COMM_ID_BYTES] */);
+int rvo_comm_create(int device, int rank, int world, const uint8_t* id, rvo_comm** out);
+int rvo_comm_destroy(rvo_comm* comm);
+int rvo_gather_trajectories(rvo_comm* comm, const void* local_dev, size_t bytes_per_rank, void* all_dev /* world * bytes_per_rank */);
 
 /* ---- per-stage dump accessors (parity tests; the inspection surface of rgbdvo/pyramid.hpp:62-151 and
  * rgbdvo/motion_estimate.hpp:56-74) ---- */

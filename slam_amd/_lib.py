@@ -53,7 +53,11 @@ SYMBOLS = [
     "rvo_get_level_info", "rvo_get_level_image", "rvo_get_grid_keypoints", "rvo_get_keypoints",
     "rvo_get_descriptors", "rvo_get_matches", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_select", "rvo_profile_read",
     "rvo_selftest_stdalgo", "rvo_bgr_to_gray_dev", "rvo_depth_to_point_cloud_dev", "rvo_get_pair_information", "rvo_get_pair_information_noalloc", "rvo_set_pair_chunks", "rvo_wait_peer",
+    "rvo_streams_record", "rvo_trajectories_dev", "rvo_get_trajectories",
+    "rvo_comm_get_unique_id", "rvo_comm_create", "rvo_comm_destroy", "rvo_gather_trajectories",
 ]
+TRAJ_DOUBLES = 16   # RVO_TRAJ_DOUBLES
+COMM_ID_BYTES = 128  # RVO_COMM_ID_BYTES
 
 _LIB = None
 
@@ -132,6 +136,13 @@ def load():
     L.rvo_profile_select.argtypes = [vp, C.c_char_p]
     L.rvo_profile_read.argtypes = [vp, ip, vp, vp, vp]
     L.rvo_selftest_stdalgo.argtypes = [ip, vp, ip, ip, ip, vp]
+    L.rvo_streams_record.argtypes = [vp, ip]
+    L.rvo_trajectories_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.rvo_get_trajectories.argtypes = [vp, ip, ip, vp]
+    L.rvo_comm_get_unique_id.argtypes = [vp]
+    L.rvo_comm_create.argtypes = [ip, ip, ip, vp, C.POINTER(vp)]
+    L.rvo_comm_destroy.argtypes = [vp]
+    L.rvo_gather_trajectories.argtypes = [vp, vp, C.c_size_t, vp]
     L.rvo_default_vo_params.argtypes = [C.POINTER(Params)]
     L.rvo_default_fm_params.argtypes = [C.POINTER(Params)]
     _LIB = L

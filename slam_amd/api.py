@@ -244,6 +244,22 @@ class Context:
         self._chk(self.L.rvo_get_stream_results(self.h, n_streams, out))
         return [stream_result_to_dict(r) for r in out]
 
+    def streams_record(self, max_steps: int):
+        """Keep the trajectories on the device: every later stream step appends one row per stream (rvo_streams_record)."""
+        self._chk(self.L.rvo_streams_record(self.h, max_steps))
+
+    def trajectories(self, n_streams: int, steps: int) -> np.ndarray:
+        """[n_streams, steps, 16]: pose 3x4, status, num_inliers, rc, used_fallback per recorded step; synchronises."""
+        out = np.zeros((n_streams, steps, _lib.TRAJ_DOUBLES))
+        self._chk(self.L.rvo_get_trajectories(self.h, n_streams, steps, _ptr(out)))
+        return out
+
+    def trajectories_dev(self):
+        """(device pointer, steps recorded, max_steps) of the [stream][max_steps][16] trajectory buffer."""
+        p, n, cap = C.c_void_p(), C.c_int32(), C.c_int32()
+        self._chk(self.L.rvo_trajectories_dev(self.h, C.byref(p), C.byref(n), C.byref(cap)))
+        return p.value, n.value, cap.value
+
     def stream_results_dev_ptr(self) -> int:
         p = C.c_void_p()
         self._chk(self.L.rvo_stream_results_dev(self.h, C.byref(p)))

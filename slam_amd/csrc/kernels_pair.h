@@ -1590,13 +1590,22 @@ __global__ void k_stream_post1(StreamState* st, int n, PairBufs pb) {
 }
 
 // vo.cpp:145-163: retry result, failure report, keyframe decision; fills the per-stream result record
-__global__ void k_stream_post2(StreamState* st, int n, StreamParams sp, PairBufs pb, rvo_stream_result* out) {
+// traj (may be null): this step's row of the device-side trajectory, [stream][traj_cap][RVO_TRAJ_DOUBLES] with the step
+// offset already applied: pose 3x4, status, inliers, rc.
+__device__ inline void traj_write(double* traj, int traj_cap, int s, const rvo_stream_result& o) {
+  if (!traj) return;
+  double* t = traj + (size_t)s * traj_cap * RVO_TRAJ_DOUBLES;
+  for (int k = 0; k < 12; k++) t[k] = o.pose[k];
+  t[12] = (double)o.status; t[13] = (double)o.num_inliers; t[14] = (double)o.rc; t[15] = (double)o.used_fallback;
+}
+
+__global__ void k_stream_post2(StreamState* st, int n, StreamParams sp, PairBufs pb, rvo_stream_result* out, double* traj, int traj_cap) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   StreamState& S = st[s];
   rvo_stream_result& o = out[s];
   o.used_fallback = 0;
-  if (!S.processed) { o.rc = 0; o.fast_threshold = S.fast_thr; o.keyframe_changed = S.ref_changed_flag; return; }
+  if (!S.processed) { o.rc = 0; o.fast_threshold = S.fast_thr; o.keyframe_changed = S.ref_changed_flag; traj_write(traj, traj_cap, s, o); return; }
   o.rc = 1;
   if (S.estimate) {
     const rvo_pair_result& r = pb.result[s];
@@ -1622,6 +1631,7 @@ __global__ void k_stream_post2(StreamState* st, int n, StreamParams sp, PairBufs
   for (int k = 0; k < 36; k++) o.cov[k] = S.cov[k];
   o.fast_threshold = S.fast_thr;
   o.keyframe_changed = S.ref_changed_flag;
+  traj_write(traj, traj_cap, s, o);
 }
 
 // ------------------------------------------------------------------ self-test of wave_stdalgo.h (one wave)

@@ -67,6 +67,8 @@ struct rvo_ctx {
   rvo_stream_result* d_stream_res = nullptr;
   int n_streams = 0;
   int32_t* d_sslots = nullptr;  // [2n]: current slot (-1 = warm-up skip), FAST threshold (device-written)
+  double* d_traj = nullptr;     // rvo_streams_record: [n_streams][traj_cap][RVO_TRAJ_DOUBLES]
+  int traj_cap = 0, traj_steps = 0, traj_streams = 0;
   double* d_pinit = nullptr;
   double* d_info = nullptr;  // [max_pairs][36] edge information matrices
   int lds_rot = 0, lds_match = 0, lds_clique = 0;
@@ -637,6 +639,7 @@ int rvo_profile_read(rvo_ctx* c, int cap, const char** names, float* total_ms, i
 }
 
 #include "rvo_pair_api.inc"
+#include "rvo_comm.inc"
 
 // ---------------------------------------------------------------- the entry point that allocates nothing
 // rvo_get_pair_information with its staging area in the file-scope `scratch` array instead of the context's d_info:

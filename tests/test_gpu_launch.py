@@ -38,3 +38,32 @@ def test_library_before_torch_in_one_process():
     assert "avail True" in lines and "45" in lines and "ok" in lines, out.stdout
     maps_line = [l for l in out.stdout.splitlines() if l.startswith("hip runtimes mapped:")]
     assert maps_line and maps_line[0].split(":")[1].split()[0] == "1", out.stdout
+
+
+def test_cabi_rccl_communicator_two_ranks():
+    """rvo_comm_* across two real processes.  On the one-GPU box both ranks name the same device and RCCL must refuse it
+    with an error code on BOTH ranks (no hang, no abort); on a node with two GPUs the gather itself is checked."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_two_ranks.py")], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("[")][-1])
+    assert [r["rank"] for r in res] == [0, 1]
+    if res[0]["devices"] >= 2:
+        for r in res:
+            assert r["gathered"] == [0.0] * 4 + [1.0] * 4, r
+    else:
+        for r in res:
+            assert "ncclCommInitRank" in r.get("error", ""), r
+
+
+def test_run_streams_gpus_2_end_to_end(tmp_path):
+    """configs[2] in miniature through its own launcher: 2 ranks x 8 streams, device-side trajectories, final gather."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_streams.py"), "--gpus", "2", "--streams", "16",
+                          "--frames", "5", "--out", str(tmp_path)], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["gather_ranks"] == 2 and d["streams"] == 16
+    assert d["estimates_ok"] == d["estimates"] == 16 * 4
+    assert d["max_abs_pose_err_vs_truth"] < 5e-3
+    assert os.path.exists(tmp_path / "stream_0000.vertices")

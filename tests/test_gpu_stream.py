@@ -175,3 +175,42 @@ def test_512_streams_on_two_contexts_configs2_per_gpu_shape(intr640):
         v.close()
     for c in ctxs:
         c.close()
+
+
+def test_device_side_trajectories_and_world1_gather(scene, intr640):
+    """rvo_streams_record: rows appended on the device equal the per-step host results; rows beyond max_steps are not
+    recorded; rvo_gather_trajectories at world size 1 (degenerate gather) returns the input block."""
+    import torch
+    from slam_amd.api import Context, default_params
+    from slam_amd.dist import RcclComm, gather_trajectories_rccl, make_rccl_comm
+    n, T, cap = 3, 6, 5
+    seqs = [list(synth.make_sequence(T, seed=70 + s, intr=intr640, scene=scene)) for s in range(n)]
+    ctx = Context(intr640, default_params(warmup_frames=2), max_frames=3 * n, max_pairs=n)
+    ctx.streams_reset(n)
+    ctx.streams_record(cap)
+    per_step = []
+    for t in range(T):
+        res = ctx.stream_step(np.stack([seqs[s][t][0] for s in range(n)]), np.stack([seqs[s][t][1] for s in range(n)]), n)
+        per_step.append(res)
+    ptr, steps, mx = ctx.trajectories_dev()
+    assert steps == cap and mx == cap and ptr
+    traj = ctx.trajectories(n, cap)
+    for t in range(cap):
+        for s in range(n):
+            r = per_step[t][s]
+            assert np.array_equal(traj[s, t, :12].reshape(3, 4), r["pose"])
+            assert traj[s, t, 12:].tolist() == [r["status"], r["num_inliers"], r["rc"], float(r["used_fallback"])]
+    assert np.array_equal(ctx.trajectories(2, 3), traj[:2, :3])
+    with pytest.raises(Exception):
+        ctx.trajectories(n, cap + 1)
+    # degenerate gather through the C ABI (world of one: no RCCL needed, same call)
+    comm = make_rccl_comm(0)
+    assert isinstance(comm, RcclComm) and comm.world == 1
+    local = torch.from_numpy(traj).cuda()
+    allt = gather_trajectories_rccl(comm, local)
+    assert np.array_equal(allt.cpu().numpy(), traj)
+    comm.close()
+    # librccl is reachable: a unique id can be drawn (what rank 0 does before a real multi-GPU gather)
+    uid = RcclComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.close()
