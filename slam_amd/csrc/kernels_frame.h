@@ -129,6 +129,7 @@ __device__ inline int gauss_tap(F at, int n, int r) {
 // multiplies never carry between the halves); the first/last output of a line takes the reference's edge formulas
 // through gauss_tap.
 __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots, int lvl) {
+  RVO_OCC_SCOPE(1, 16);
   const LevelGeom S = g.lv[lvl - 1], D = g.lv[lvl];
   int tile, fi;  // XCD-aware: the tiles of a frame share source lines
   xcd_map(gridDim.x * gridDim.y, gridDim.z, blockIdx.y * gridDim.x + blockIdx.x, blockIdx.z, &tile, &fi);
@@ -350,6 +351,7 @@ struct FastLds {  // byte offsets into dynamic LDS, computed on the host (all mu
 template <int TPC, int SPC>
 __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, FastLds L, const int32_t* __restrict__ slots,
                                                    const int32_t* __restrict__ thr) {
+  RVO_OCC_SCOPE(2, 32);
   extern __shared__ __align__(16) uint8_t lds[];
   uint8_t* s_tile = lds;
   uint8_t* s_score = lds + L.off_score;
@@ -701,6 +703,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
 // ------------------------------------------------------------------ keypoint records + XYZ
 // grid (levels, n_frames), 256 threads.
 __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots) {
+  RVO_OCC_SCOPE(3, 1);
   __shared__ int s_wave[4];
   __shared__ int s_red[8];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -785,6 +788,7 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
 // k_fast_grid) are copied into the level's compact order.  grid (ceil(kp_total*5/256), n_frames): one 16-byte piece
 // per thread, five consecutive threads per keypoint.  Runs after k_build_keypoints (reads kp_src / kp_cnt).
 __global__ __launch_bounds__(256) void k_descriptors(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots) {
+  RVO_OCC_SCOPE(4, 16);
   const int slot = slots[blockIdx.y];
   if (slot < 0) return;
   const int t = blockIdx.x * 256 + threadIdx.x;

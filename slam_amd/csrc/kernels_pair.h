@@ -63,19 +63,23 @@ __device__ inline DQuat R_to_quat(const double* m) {
     q.x = (m[7] - m[5]) * t;
     q.y = (m[2] - m[6]) * t;
     q.z = (m[3] - m[1]) * t;
-  } else {
+  } else {  // Eigen's branch on the largest diagonal element, written out per case (static indexing: no scratch memory)
     int i = 0;
     if (m[4] > m[0]) i = 1;
     if (m[8] > m[i * 4]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(m[i * 4] - m[j * 4] - m[k * 4] + 1.0);
-    double v[3];
-    v[i] = 0.5 * t;
-    t = 0.5 / t;
-    q.w = (m[k * 3 + j] - m[j * 3 + k]) * t;
-    v[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
-    v[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
-    q.x = v[0]; q.y = v[1]; q.z = v[2];
+    if (i == 0) {
+      t = sqrt(m[0] - m[4] - m[8] + 1.0);
+      q.x = 0.5 * t; t = 0.5 / t;
+      q.w = (m[7] - m[5]) * t; q.y = (m[3] + m[1]) * t; q.z = (m[6] + m[2]) * t;
+    } else if (i == 1) {
+      t = sqrt(m[4] - m[8] - m[0] + 1.0);
+      q.y = 0.5 * t; t = 0.5 / t;
+      q.w = (m[2] - m[6]) * t; q.z = (m[7] + m[5]) * t; q.x = (m[1] + m[3]) * t;
+    } else {
+      t = sqrt(m[8] - m[0] - m[4] + 1.0);
+      q.z = 0.5 * t; t = 0.5 / t;
+      q.w = (m[3] - m[1]) * t; q.x = (m[2] + m[6]) * t; q.y = (m[5] + m[7]) * t;
+    }
   }
   return q;
 }
@@ -197,6 +201,7 @@ __device__ inline void block_sum_lds(double* v, double* s_big) {
 // grid (n_pairs), 256 threads, dynamic LDS = 5 * npx floats + 64 doubles.
 // mode 0: write q0 only; mode 1: also init_pose = Identity.rotate(q0) (fm.cpp:41-47).
 __global__ __launch_bounds__(256) void k_init_rotation(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, int mode) {
+  RVO_OCC_SCOPE(5, 1);
   extern __shared__ __align__(16) uint8_t lds[];
   const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x;
   if (!pb.active[pair]) return;
@@ -331,7 +336,12 @@ __global__ __launch_bounds__(256) void k_init_rotation(FrameBufs fb, FrameGeom g
 }
 
 // ------------------------------------------------------------------ matching
-#define MATCH_THREADS 1024
+// 256 threads: a workgroup of 4 waves x 96 VGPRs + 24 KB of LDS fits into the room ONE retiring k_fast_grid workgroup
+// leaves on a CU (the other batch's FAST stage floods every CU with 7 workgroups), so k_match is dispatched while FAST
+// runs; with 1024 threads (faster alone: 0.12 vs 0.17 ms) it waited for FAST to drain: 0.34 ms in the pipeline.
+#ifndef MATCH_THREADS
+#define MATCH_THREADS 256
+#endif
 #define MATCH_WAVES (MATCH_THREADS / 64)
 #define MATCH_QCAP 256  // per-wave candidate queue entries; flushed when fewer than 64 slots are left
 
@@ -364,6 +374,7 @@ __device__ inline uint32_t sad80(const uint8_t* a, const uint8_t* b) {
 __host__ __device__ inline int match_max_runs(int cap) { return (cap + 63) / 64 + 1; }
 __host__ __device__ inline int match_lds_bytes(int cap) { return cap * 16 + match_max_runs(cap) * 16 + MATCH_WAVES * MATCH_QCAP * 4 + 128; }
 __global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, EstParams ep) {
+  RVO_OCC_SCOPE(6, 1);
   extern __shared__ __align__(16) uint8_t lds[];
   const int lvl = blockIdx.x, pair = blockIdx.y + pb.pair0, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (!pb.active[pair]) return;
@@ -553,6 +564,7 @@ __device__ inline int group16_sum(int v) {
 // grid (ceil(kp_total/16), n_pairs), 256 threads: 16 lanes per match, 5 descriptor taps per lane; all sums are exact
 // int32, so the lane split does not change any value.  Branches below are uniform within a 16-lane group.
 __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
+  RVO_OCC_SCOPE(7, 16);
   const int pair = blockIdx.y + pb.pair0;
   if (!pb.active[pair]) return;
   const int gl = threadIdx.x & (REFINE_GROUP - 1);
@@ -712,6 +724,7 @@ __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairB
 // Gating + refined record, motion_estimate.cpp:360-376: one thread per match (a kernel of its own so that its fp64
 // lookups do not add to the register budget of the ESM loop above).  grid (ceil(mcap/256), n_pairs), 256 threads.
 __global__ __launch_bounds__(256) void k_refine_finish(FrameBufs fb, FrameGeom g, PairBufs pb) {
+  RVO_OCC_SCOPE(8, 4);
   const int pair = blockIdx.y + pb.pair0;
   if (!pb.active[pair]) return;
   const int N = pb.n_matches[pair];
@@ -806,6 +819,7 @@ __global__ __launch_bounds__(256) void k_refine_finish(FrameBufs fb, FrameGeom g
 // coordinate (depth.cpp:137-147 quirk) makes the reference's comparison false; the fp32 test classifies it as false too.
 typedef float f2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) {
+  RVO_OCC_SCOPE(9, 4);
   __shared__ float s_c[(CONS_TILE + 32) * 6];
   const int pair = blockIdx.y + pb.pair0;
   if (!pb.active[pair]) return;
@@ -915,14 +929,20 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
 // ------------------------------------------------------------------ sort + greedy clique
 // grid (n_pairs), CLIQUE_WAVES*64 threads; dynamic LDS = clique_lds_bytes(mcap, cwords).  All waves sort; wave 0
 // then walks the sorted candidates (8 waves measured best).
+#ifndef CLIQUE_WAVES
 #define CLIQUE_WAVES 8
+#endif
 __host__ __device__ inline int clique_ctl_ints() { return 4 + SORT_QCAP * 2 + CLIQUE_WAVES * SORT_STACK * 2; }
 // keys | accepted mask | sort control | scratch: the sort's 12*mcap bytes, reused as the 64 x (cwords+1) staged rows
 __host__ __device__ inline int clique_lds_bytes(int mcap, int cwords) {
   const int scratch = mcap * 12 > 256 * (cwords + 1) ? mcap * 12 : 256 * (cwords + 1);
   return mcap * 4 + cwords * 4 + clique_ctl_ints() * 4 + scratch + 64;
 }
-__global__ __launch_bounds__(CLIQUE_WAVES * 64) void k_clique(PairBufs pb) {
+#ifndef CLIQUE_MIN_WAVES
+#define CLIQUE_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(CLIQUE_WAVES * 64, CLIQUE_MIN_WAVES) void k_clique(PairBufs pb) {
+  RVO_OCC_SCOPE(10, 1);
   extern __shared__ __align__(16) uint8_t lds[];
   const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x, lane = tid & 63;
   if (!pb.active[pair]) return;
@@ -1083,9 +1103,10 @@ __global__ __launch_bounds__(CLIQUE_WAVES * 64) void k_clique(PairBufs pb) {
 struct JacMats { double P[12], Ju[24], Jv[24], Jw[24]; };
 
 // computeProjectionJacobian, motion_estimate.cpp:1061-1101
-__device__ inline void forward_jac_mats(const double* prm, double fx, double px, double py, JacMats& m) {
+// sc = sin/cos of roll, pitch, yaw: {sr, cr, sp, cp, sy, cy}
+__device__ inline void forward_jac_mats(const double* prm, const double* sc, double fx, double px, double py, JacMats& m) {
   const double tx = prm[0], ty = prm[1], tz = prm[2];
-  const double sr = sin(prm[3]), cr = cos(prm[3]), sp = sin(prm[4]), cp = cos(prm[4]), sy = sin(prm[5]), cy = cos(prm[5]);
+  const double sr = sc[0], cr = sc[1], sp = sc[2], cp = sc[3], sy = sc[4], cy = sc[5];
   const double P[12] = {fx * cp * cy - px * sp, px * cp * sr - fx * (cr * sy - cy * sp * sr), fx * (sr * sy + cr * cy * sp) + px * cp * cr, fx * tx + px * tz,
                         fx * cp * sy - py * sp, fx * (cr * cy + sp * sr * sy) + py * cp * sr, py * cp * cr - fx * (cy * sr - cr * sp * sy), fx * ty + py * tz,
                         -sp, cp * sr, cp * cr, tz};
@@ -1107,9 +1128,9 @@ __device__ inline void forward_jac_mats(const double* prm, double fx, double px,
 }
 
 // computeReverseProjectionJacobian, motion_estimate.cpp:1133-1184
-__device__ inline void reverse_jac_mats(const double* prm, double fx, double px, double py, JacMats& m) {
+__device__ inline void reverse_jac_mats(const double* prm, const double* sc, double fx, double px, double py, JacMats& m) {
   const double tx = prm[0], ty = prm[1], tz = prm[2];
-  const double sr = sin(prm[3]), cr = cos(prm[3]), sp = sin(prm[4]), cp = cos(prm[4]), sy = sin(prm[5]), cy = cos(prm[5]);
+  const double sr = sc[0], cr = sc[1], sp = sc[2], cp = sc[3], sy = sc[4], cy = sc[5];
   const double P[12] = {
       px * (sr * sy + cr * cy * sp) + fx * cp * cy, fx * cp * sy - px * (cy * sr - cr * sp * sy), px * cp * cr - fx * sp,
       -px * (tx * (sr * sy + cr * cy * sp) - ty * (cy * sr - cr * sp * sy) + tz * cp * cr) - fx * (tx * cp * cy - tz * sp + ty * cp * sy),
@@ -1189,262 +1210,7 @@ __device__ inline void inverse6(const double* A, double* inv) {
     for (int j = 0; j < 6; j++) inv[i * 6 + j] = a[i][6 + j];
 }
 
-struct GnShared {
-  JacMats jac[2];          // forward, reverse
-  double P[2][12];         // K(fx,fx)*motion and K(fx,fx)*motion^-1 for the error at the current estimate
-  double PN[2][12];        // same at the trial estimate
-  double est[6], next[6], delta[6];
-  double motion[12], nmotion[12];
-  double final_sse;
-  int stop, status, n_inl;
-};
-
-#define GN_THREADS 512
-// grid (n_pairs), GN_THREADS threads: one workgroup per pair, two waves per SIMD (207 VGPRs; with the Jacobians
-// hoisted into registers the kernel needed 502 and could only run one).
-__global__ __launch_bounds__(GN_THREADS) void k_gn(PairBufs pb, CamParams cam, EstParams ep) {
-  __shared__ GnShared S;
-  __shared__ double s_big[27 * 256 + 27 * 16];
-  const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x;
-  if (!pb.active[pair]) return;
-  const int N = pb.n_matches[pair];
-  const size_t mb = (size_t)pair * pb.mcap;
-  rvo_pair_result* res = pb.result + pair;
-  const double fx = cam.fx, px = cam.cx, py = cam.cy;
-
-  if (tid == 0) {
-    S.n_inl = res->num_inliers;
-    S.status = RVO_SUCCESS;  // motion_estimate.cpp:190-192
-    for (int k = 0; k < 12; k++) S.motion[k] = pb.init_pose[pair * 12 + k];
-    for (int k = 0; k < 36; k++) res->cov[k] = 0;
-  }
-  __syncthreads();
-
-  auto err_sse = [&](const double* Pf, const double* Pr) -> double {  // sum of squared bidirectional errors over inliers
-    double s = 0;
-    for (int i = tid; i < N; i += GN_THREADS) {
-      if (!pb.m_inlier[mb + i]) continue;
-      const double* t = pb.m_xyz + (mb + i) * 3;
-      const double* r = pb.m_rxyz + (mb + i) * 3;
-      double u = dot4(Pf, t[0], t[1], t[2], 1.0), v = dot4(Pf + 4, t[0], t[1], t[2], 1.0), w = dot4(Pf + 8, t[0], t[1], t[2], 1.0);
-      double e0 = u / w - pb.m_rrect[(mb + i) * 2], e1 = v / w - pb.m_rrect[(mb + i) * 2 + 1];
-      s += e0 * e0; s += e1 * e1;
-      u = dot4(Pr, r[0], r[1], r[2], 1.0); v = dot4(Pr + 4, r[0], r[1], r[2], 1.0); w = dot4(Pr + 8, r[0], r[1], r[2], 1.0);
-      e0 = u / w - pb.m_rect[(mb + i) * 2]; e1 = v / w - pb.m_rect[(mb + i) * 2 + 1];
-      s += e0 * e0; s += e1 * e1;
-    }
-    return s;
-  };
-  auto set_P = [&](const DIso& m, double* Pf, double* Pr) {
-    proj_matrix(fx, fx, px, py, m, Pf);  // fx on both axes, motion_estimate.cpp:1221-1223
-    proj_matrix(fx, fx, px, py, iso_inverse(m), Pr);
-  };
-
-  // refineMotionEstimate() -> refineMotionEstimateBidirectional, motion_estimate.cpp:610-682, 1208-1331
-  // covariance = (M'M)^-1 at the current parameters S.est, motion_estimate.cpp:1319-1329
-  auto covariance = [&]() {
-    __syncthreads();
-    if (tid == 0) forward_jac_mats(S.est, fx, px, py, S.jac[0]);
-    if (tid == 64) reverse_jac_mats(S.est, fx, px, py, S.jac[1]);
-    __syncthreads();
-    double acc[21];
-#pragma unroll
-    for (int k = 0; k < 21; k++) acc[k] = 0;
-    for (int item = tid; item < 2 * N; item += GN_THREADS) {
-      const int i = item >> 1, dir = item & 1;
-      if (!pb.m_inlier[mb + i]) continue;
-      {
-        const JacMats& J = S.jac[dir];
-        const double* pt = (dir ? pb.m_rxyz : pb.m_xyz) + (mb + i) * 3;
-        const double x = pt[0], y = pt[1], z = pt[2];
-        const double u = dot4(J.P, x, y, z, 1.0), v = dot4(J.P + 4, x, y, z, 1.0), w = dot4(J.P + 8, x, y, z, 1.0);
-        const double w_inv_sq = 1 / (w * w);
-        double ru[6], rv[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-          const double du = dot4(J.Ju + 4 * k, x, y, z, 1.0), dv = dot4(J.Jv + 4 * k, x, y, z, 1.0), dw = dot4(J.Jw + 4 * k, x, y, z, 1.0);
-          ru[k] = (du * w - dw * u) * w_inv_sq;
-          rv[k] = (dv * w - dw * v) * w_inv_sq;
-        }
-        int q = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-          for (int b = a; b < 6; b++) { acc[q] += ru[a] * ru[b]; acc[q] += rv[a] * rv[b]; q++; }
-      }
-    }
-    block_sum_lds<21, GN_THREADS>(acc, s_big);
-    if (tid == 0) {
-      double A[36], Ainv[36];
-      int q = 0;
-      for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { A[a * 6 + b] = acc[q]; A[b * 6 + a] = acc[q]; q++; }
-      inverse6(A, Ainv);
-      for (int k = 0; k < 36; k++) res->cov[k] = Ainv[k];
-    }
-    __syncthreads();
-  };
-
-  // The reference computes the covariance at the end of every refineMotionEstimate(); the second call overwrites the
-  // first one's, so the first is only computed here when the second call is going to bail out (too few inliers left
-  // after the reprojection pruning) and leave it standing.
-  auto refine = [&](bool with_cov) {
-    __syncthreads();
-    if (S.n_inl < ep.min_features) {
-      if (tid == 0) S.status = RVO_INSUFFICIENT_INLIERS;
-      __syncthreads();
-      return;
-    }
-    if (tid == 0) {
-      DIso m;
-      iso_load(m, S.motion);
-      iso_to_params(m, S.est);
-      set_P(m, S.P[0], S.P[1]);
-      S.stop = 0;
-    }
-    __syncthreads();
-    {
-      double v[1] = {err_sse(S.P[0], S.P[1])};
-      block_sum_lds<1, GN_THREADS>(v, s_big);
-      if (tid == 0) S.final_sse = v[0];
-    }
-    for (int it = 0; it < 6; it++) {
-      if (tid == 0) forward_jac_mats(S.est, fx, px, py, S.jac[0]);
-      if (tid == 64) reverse_jac_mats(S.est, fx, px, py, S.jac[1]);
-      __syncthreads();
-      double acc[27];
-#pragma unroll
-      for (int k = 0; k < 27; k++) acc[k] = 0;
-      // one (match, direction) item per thread and trip: the Jacobian matrices are read from LDS by direction, which
-      // keeps them out of the register file (two waves per SIMD instead of one)
-      for (int item = tid; item < 2 * N; item += GN_THREADS) {
-        const int i = item >> 1, dir = item & 1;
-        if (!pb.m_inlier[mb + i]) continue;
-        {
-          const JacMats& J = S.jac[dir];
-          const double* Pe = S.P[dir];
-          const double* pt = (dir ? pb.m_rxyz : pb.m_xyz) + (mb + i) * 3;
-          const double* pj = (dir ? pb.m_rect : pb.m_rrect) + (mb + i) * 2;
-          const double x = pt[0], y = pt[1], z = pt[2];
-          const double u = dot4(J.P, x, y, z, 1.0), v = dot4(J.P + 4, x, y, z, 1.0), w = dot4(J.P + 8, x, y, z, 1.0);
-          const double w_inv_sq = 1 / (w * w);
-          double ru[6], rv[6];
-#pragma unroll
-          for (int k = 0; k < 6; k++) {
-            const double du = dot4(J.Ju + 4 * k, x, y, z, 1.0), dv = dot4(J.Jv + 4 * k, x, y, z, 1.0), dw = dot4(J.Jw + 4 * k, x, y, z, 1.0);
-            ru[k] = (du * w - dw * u) * w_inv_sq;
-            rv[k] = (dv * w - dw * v) * w_inv_sq;
-          }
-          const double eu = dot4(Pe, x, y, z, 1.0), ev = dot4(Pe + 4, x, y, z, 1.0), ew = dot4(Pe + 8, x, y, z, 1.0);
-          const double e0 = eu / ew - pj[0], e1 = ev / ew - pj[1];
-          int q = 0;
-#pragma unroll
-          for (int a = 0; a < 6; a++) {
-#pragma unroll
-            for (int b = a; b < 6; b++) { acc[q] += ru[a] * ru[b]; acc[q] += rv[a] * rv[b]; q++; }
-            acc[21 + a] += ru[a] * e0;
-            acc[21 + a] += rv[a] * e1;
-          }
-        }
-      }
-      block_sum_lds<27, GN_THREADS>(acc, s_big);
-      if (tid == 0) {
-        double A[36], Ainv[36], delta[6], next[6];
-        int q = 0;
-        for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { A[a * 6 + b] = acc[q]; A[b * 6 + a] = acc[q]; q++; }
-        inverse6(A, Ainv);
-        for (int a = 0; a < 6; a++) {
-          double s = 0;
-          for (int b = 0; b < 6; b++) s += (-Ainv[a * 6 + b]) * acc[21 + b];
-          delta[a] = s;
-          next[a] = S.est[a] + s;
-        }
-        const DIso nest = iso_from_params(next);
-        set_P(nest, S.PN[0], S.PN[1]);
-        for (int a = 0; a < 6; a++) { S.next[a] = next[a]; S.delta[a] = delta[a]; }
-        iso_store(nest, S.nmotion);
-      }
-      __syncthreads();
-      double v[1] = {err_sse(S.PN[0], S.PN[1])};
-      block_sum_lds<1, GN_THREADS>(v, s_big);
-      if (tid == 0) {
-        const double sse = v[0];
-        if (sse > S.final_sse) {
-          S.stop = 1;
-        } else {
-          for (int a = 0; a < 6; a++) S.est[a] = S.next[a];
-          S.final_sse = sse;
-          for (int k = 0; k < 12; k++) { S.motion[k] = S.nmotion[k]; S.P[0][k] = S.PN[0][k]; S.P[1][k] = S.PN[1][k]; }
-          const double rt = 0.01 * M_PI / 180;
-          const double* d = S.delta;
-          if (fabs(d[0]) < 0.0001 && fabs(d[1]) < 0.0001 && fabs(d[2]) < 0.0001 && fabs(d[3]) < rt && fabs(d[4]) < rt && fabs(d[5]) < rt) S.stop = 1;
-        }
-      }
-      __syncthreads();
-      if (S.stop) break;
-    }
-    if (with_cov) covariance();
-  };
-
-  // computeReprojectionError(), motion_estimate.cpp:684-720 (K uses fx, fy)
-  __shared__ double s_mean;
-  if (tid == 0) s_mean = 0;
-  auto reproj = [&]() {
-    __syncthreads();
-    if (S.status != RVO_SUCCESS) return;
-    if (tid == 0) {
-      DIso m;
-      iso_load(m, S.motion);
-      proj_matrix(cam.fx, cam.fy, cam.cx, cam.cy, m, S.PN[0]);
-    }
-    __syncthreads();
-    double v[1] = {0};
-    for (int i = tid; i < N; i += GN_THREADS) {
-      if (!pb.m_inlier[mb + i]) continue;
-      const double* t = pb.m_xyz + (mb + i) * 3;
-      const double h0 = dot4(S.PN[0], t[0], t[1], t[2], 1.0), h1 = dot4(S.PN[0] + 4, t[0], t[1], t[2], 1.0), h2 = dot4(S.PN[0] + 8, t[0], t[1], t[2], 1.0);
-      const double ex = pb.m_rrect[(mb + i) * 2] - h0 / h2, ey = pb.m_rrect[(mb + i) * 2 + 1] - h1 / h2;
-      const double e = sqrt(ex * ex + ey * ey);
-      pb.m_reproj[mb + i] = e;
-      v[0] += e;
-    }
-    block_sum_lds<1, GN_THREADS>(v, s_big);
-    if (tid == 0) s_mean = v[0] / (double)S.n_inl;
-    __syncthreads();
-  };
-
-  refine(false);
-  const bool refined1 = S.status == RVO_SUCCESS;  // (uniform: read after refine()'s closing barrier)
-  reproj();
-  // drop inliers with a high reprojection error, motion_estimate.cpp:203-214
-  {
-    __syncthreads();
-    int fails = 0;
-    for (int i = tid; i < N; i += GN_THREADS)
-      if (pb.m_inlier[mb + i] && pb.m_reproj[mb + i] > ep.inlier_max_reprojection_error) fails++;
-    double v[1] = {(double)fails};
-    block_sum_lds<1, GN_THREADS>(v, s_big);
-    if (tid == 0) { S.n_inl -= (int)v[0]; res->num_reprojection_failures = (int)v[0]; }
-    __syncthreads();
-    // the second refine will bail out (too few inliers left): the first estimate's covariance, over the inliers it
-    // was estimated from, is what the reference leaves standing
-    if (refined1 && S.n_inl < ep.min_features) covariance();
-    for (int i = tid; i < N; i += GN_THREADS)
-      if (pb.m_inlier[mb + i] && pb.m_reproj[mb + i] > ep.inlier_max_reprojection_error) pb.m_inlier[mb + i] = 0;
-    __syncthreads();
-  }
-  refine(true);
-  reproj();
-  __syncthreads();
-  if (tid == 0) {
-    int status = S.status;
-    if (s_mean > ep.max_mean_reprojection_error) status = RVO_REPROJECTION_ERROR;
-    res->status = status;
-    res->num_matches = N;
-    res->num_inliers = S.n_inl;
-    res->mean_reprojection_error = s_mean;
-    for (int k = 0; k < 12; k++) res->pose[k] = S.motion[k];
-  }
-}
+#include "kernels_gn.h"
 
 // ------------------------------------------------------------------ edge information for the pose graph
 // PoseGraphOptimizer::AddEdge (pose_graph.cpp:254-270): info = edge.covariance.inverse(), one 6x6 partial-pivot

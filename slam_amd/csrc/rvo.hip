@@ -71,7 +71,7 @@ struct rvo_ctx {
   int traj_cap = 0, traj_steps = 0, traj_streams = 0;
   double* d_pinit = nullptr;
   double* d_info = nullptr;  // [max_pairs][36] edge information matrices
-  int lds_rot = 0, lds_match = 0, lds_clique = 0;
+  int lds_rot = 0, lds_match = 0, lds_clique = 0, lds_gn = 0;
   // pinned ring for small host->device argument arrays (slot lists, thresholds, initial poses)
   static const int kRing = 32;
   uint8_t* h_ring = nullptr;

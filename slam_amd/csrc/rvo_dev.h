@@ -116,6 +116,30 @@ __device__ inline const uint8_t* level_img(const FrameBufs& fb, const FrameGeom&
   return lvl == 0 ? fb.l0_tab[slot] : fb.img + (size_t)slot * g.img_bytes + g.lv[lvl].img_off;
 }
 
+// ---- occupancy timeline (one-off builds with -DRVO_OCC only, tools/exp_occupancy.py): every workgroup adds +1 / -1
+// to a histogram of 10 us buckets of the constant 100 MHz clock when it starts / ends, per kernel kind; the running sum
+// over the buckets is the number of resident workgroups of that kernel over time, without any profiler in the way.
+#ifdef RVO_OCC
+#define RVO_OCC_KINDS 16
+#define RVO_OCC_BUCKETS 65536
+__device__ int g_occ[RVO_OCC_KINDS][RVO_OCC_BUCKETS];
+struct OccScope {  // big grids are sampled (one workgroup in `sample`, counted `sample` times): the atomics must not become the bottleneck
+  int kind, sample;
+  bool on;
+  __device__ OccScope(int k, int smp) : kind(k), sample(smp) {
+    on = threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0 && (blockIdx.x + blockIdx.y * 7 + blockIdx.z * 13) % smp == 0;
+    mark(smp);
+  }
+  __device__ ~OccScope() { mark(-sample); }
+  __device__ void mark(int d) const {
+    if (on) atomicAdd(&g_occ[kind][(wall_clock64() / 1000) & (RVO_OCC_BUCKETS - 1)], d);
+  }
+};
+#define RVO_OCC_SCOPE(k, smp) OccScope occ_scope_(k, smp)
+#else
+#define RVO_OCC_SCOPE(k, smp) do { } while (0)
+#endif
+
 struct CamParams {
   double fx, fy, cx, cy;  // rectified camera (camera.cpp:7-12)
   double in_fx;           // input camera fx (motion_estimate.cpp:297-299)
