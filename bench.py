@@ -97,10 +97,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     n_pairs = a.pairs
+    t_start = time.perf_counter()
+
+    def log(msg):  # progress on stderr (a long run must not look hung; a stuck phase names itself)
+        sys.stderr.write(f"[bench r{rank} +{time.perf_counter() - t_start:6.1f}s] {msg}\n")
+        sys.stderr.flush()
 
     # synthetic inputs first (forks workers; nothing has touched the GPU yet)
     gray, depth, T_gt = make_batch(n_pairs, seed0=100000 * rank)
 
+    log("inputs made")
     import torch
     import torch.distributed as dist
     from slam_amd import synth
@@ -116,20 +122,23 @@ def main():
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # RCCL bootstrap only; the data path is xGMI
         dist.init_process_group("cpu:gloo,cuda:nccl", timeout=__import__("datetime").timedelta(seconds=180))
+    log("process group up")
     dev = torch.device("cuda", dev_index)
     d_gray = torch.from_numpy(gray).to(dev)
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
 
     intr = synth.default_intrinsics(640, 480)
-    # Double buffering: two contexts (each with its own work areas and HIP streams) take alternate batches, so the
-    # latency-bound pair stages of batch k overlap the frame stages of batch k+1.  Every step is still one whole batch
-    # of n_pairs pairs through ONE C-ABI call; within a context the batch then runs as a single chunk.
-    n_ctx = int(os.environ.get("RVO_BENCH_CONTEXTS", "2"))
-    pipe = PipelinedFrameMatcher(intr, n_pairs, device=dev_index, depth=n_ctx)
+    # Every step is one whole batch of n_pairs pairs through ONE C-ABI call on ONE context; the library's staged pipeline
+    # (rvo_set_pipeline, the default) runs the stages of successive batches on four streams, so the latency-bound tail of
+    # batch k overlaps the frame stages of batch k+1.  RVO_BENCH_CONTEXTS=2 selects round 1's arrangement instead (two
+    # contexts taking alternate batches, each batch one chain).
+    n_ctx = int(os.environ.get("RVO_BENCH_CONTEXTS", "1"))
+    pipe = PipelinedFrameMatcher(intr, n_pairs, device=dev_index, contexts=n_ctx)
     ctxs = pipe.ctxs
     if os.environ.get("RVO_PAIR_CHUNKS"):
         for c in ctxs:
             c.set_pair_chunks(int(os.environ["RVO_PAIR_CHUNKS"]))
+    log("contexts created")
     thr = ctxs[0].params.fast_init_threshold
     torch.cuda.synchronize()  # inputs are resident before anything is enqueued on the contexts' own streams
 
@@ -154,12 +163,22 @@ def main():
     # Warm-up.  With HIP events around all ~15 launches of a batch the pipeline runs about 7 % slower, so the warm-up
     # (events around every launch) only finds the dominant kernel; the timed region then brackets that kernel alone.
     noprof = bool(os.environ.get("RVO_BENCH_NOPROF"))
+    # A box that has been idle runs its first ~0.5 s of work at lower clocks (first run after a lease: 230k instead of
+    # 290k pairs/s with 10 warm-up steps = 9 ms): keep the GPU busy for a second before the W warm-up steps.  Untimed.
+    prewarm_s = float(os.environ.get("RVO_BENCH_PREWARM_S", "1.0"))
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < prewarm_s:
+        for k in range(8):
+            step(k)
+        sync_all()
+    log("clocks warm")
     if not noprof:
         for c in ctxs:
             c.profile_enable(True)
     for k in range(a.warmup):
         step(k)
     sync_all()
+    log("warm-up done")
     dom = None
     if not noprof:
         wp = read_prof()
@@ -179,6 +198,7 @@ def main():
     sync_all()
     barrier()
     dt = time.perf_counter() - t0
+    log("timed region done")
     prof_dom = read_prof() if not noprof else {}  # the dominant kernel over the timed region, on its own stream
     # the other kernels' durations (the `kernels` table): a separate pass after the timed region, events around every launch
     prof = {}
@@ -192,14 +212,17 @@ def main():
         prof = read_prof()
         for c in ctxs:
             c.profile_enable(False)
-    ctx = pipe.context_of(pipe.k - 1)  # holds the last batch's results
+    log("kernel table pass done")
+    last = pipe.k - 1
+    ctx = pipe.context_of(last)  # holds the last batch's results
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # results + final trajectory gather (RCCL all_gather of the per-pair 3x4 poses and status)
-    res = ctx.pair_results(n_pairs)
+    res = pipe.results(last)
+    sync_all()
     gather_ms = None
     gather_backend = None
     gather_ranks = None
@@ -219,9 +242,10 @@ def main():
         mine = allp[rank * n_pairs:(rank + 1) * n_pairs]
         assert np.array_equal(mine, local)  # every rank finds its own block where its rank says
 
+    log("results read, gather done")
     ok = sum(r["status"] == 1 for r in res)
     err = max(np.abs(r["pose"] - T_gt[i]).max() for i, r in enumerate(res) if r["status"] == 1) if ok else float("nan")
-    kp = [sum(ctx.level_info(s, l)["num_keypoints"] for l in range(3)) for s in range(0, 2 * n_pairs, 37)]
+    kp = [sum(ctx.level_info(int(s), l)["num_keypoints"] for l in range(3)) for s in pipe.slots_of(last)[::37]]
     stats = dict(n_frames=2 * n_pairs, n_pairs=n_pairs, mean_kp_per_frame=float(np.mean(kp)),
                  mean_matches=float(np.mean([r["num_matches"] for r in res])),
                  mean_inliers=float(np.mean([r["num_inliers"] for r in res])))
@@ -243,7 +267,7 @@ def main():
             # --pmc passes of this same command (profiles/r01_pmc_traffic.json), valid for the default launch shape
             traffic, traffic_src = None, None
             tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tp) and n_pairs == 256 and n_ctx == 2 and not os.environ.get("RVO_PAIR_CHUNKS"):
+            if os.path.exists(tp) and n_pairs == 256 and n_ctx == 1 and not os.environ.get("RVO_PAIR_CHUNKS"):
                 tj = json.load(open(tp))
                 if dom in tj["kernels"]:
                     traffic = tj["kernels"][dom]["traffic_bytes"]
@@ -259,7 +283,7 @@ def main():
         # the committed SQ counters of this same command (a --pmc pass of its own) against the live batch time
         roof_valu = None
         sp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_sq_counters.csv")
-        if os.path.exists(sp) and n_pairs == 256 and n_ctx == 2 and not os.environ.get("RVO_PAIR_CHUNKS"):
+        if os.path.exists(sp) and n_pairs == 256 and n_ctx == 1 and not os.environ.get("RVO_PAIR_CHUNKS"):
             import csv
             issue_ms = sum(float(r["valu_issue_ms_at_2.4GHz"]) * int(r["launches_per_batch"]) for r in csv.DictReader(open(sp)))
             roof_valu = dict(bound="valu-issue", issue_ms_per_batch=issue_ms, frac=issue_ms / (dt / a.steps * 1e3),
@@ -318,7 +342,7 @@ def main():
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8/int32/f64", data="synthetic",
                     config=dict(workload=f"configs[1]: {n_pairs} independent synthetic 640x480 gray+depth frame pairs "
                                          f"per GPU, 3-level pyramid, default feature grid (80x80x25), device-resident inputs",
-                                pairs_per_gpu=n_pairs, batches_in_flight=n_ctx,
+                                pairs_per_gpu=n_pairs, contexts=n_ctx, pipeline="staged (4 streams, 2 work-area sets)" if n_ctx == 1 else f"{n_ctx} contexts, alternate batches",
                                 parallelism=f"dp{world} (independent pairs, no collective in loop)"),
                     roofline=roof,
                     roofline_path=dict(bytes_per_pair=b_pair, frac=value / world * b_pair / HBM_PEAK,

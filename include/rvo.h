@@ -119,6 +119,19 @@ int rvo_set_pair_chunks(rvo_ctx* ctx, int chunks);
  * batch run beside the per-pair stages of the other (+2 % over free-running contexts, which drift into lockstep).
  * A peer that has not submitted anything yet does not block. */
 int rvo_wait_peer(rvo_ctx* ctx, rvo_ctx* peer);
+/* No counterpart in the reference: how rvo_match_frames_dev runs its batches.  staged = 1 (default; env RVO_STAGED=0
+ * overrides at rvo_create): the stages of a batch run on four HIP streams (frames / initial rotation / pair stages /
+ * clique + Gauss-Newton) on one of two sets of pair work areas, so that successive calls pipeline inside ONE context:
+ * the latency-bound tail of batch k runs beside the frame stages of batch k+1.  Rules for the caller: the frame slots of
+ * a batch are read by its pair stages, so give consecutive batches different slots (e.g. alternate two halves of the
+ * slot range) or the next batch's frame stages wait for them; results of the last two batches stay available
+ * (rvo_get_batch_results).  staged = 0: one chain per call, cut into rvo_set_pair_chunks chunks.
+ * The staged form runs on the context's own streams only (all of one priority):
+ * rvo_set_stream(ctx, s != NULL) switches it off, and rvo_set_pipeline(ctx, 1) then returns RVO_E_UNSUPPORTED. */
+int rvo_set_pipeline(rvo_ctx* ctx, int staged);
+/* Results of the staged batch submitted `batches_ago` calls ago (0 = the latest, 1 = the one before); waits for that
+ * batch only, later batches keep running. */
+int rvo_get_batch_results(rvo_ctx* ctx, int batches_ago, int n, rvo_pair_result* out);
 /* Use an existing HIP stream (hipStream_t passed as void*; NULL = the context's own). */
 int rvo_set_stream(rvo_ctx* ctx, void* hip_stream);
 int rvo_sync(rvo_ctx* ctx);

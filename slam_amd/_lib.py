@@ -54,7 +54,7 @@ SYMBOLS = [
     "rvo_get_descriptors", "rvo_get_matches", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_select", "rvo_profile_read",
     "rvo_selftest_stdalgo", "rvo_bgr_to_gray_dev", "rvo_depth_to_point_cloud_dev", "rvo_get_pair_information", "rvo_get_pair_information_noalloc", "rvo_set_pair_chunks", "rvo_wait_peer",
     "rvo_streams_record", "rvo_trajectories_dev", "rvo_get_trajectories",
-    "rvo_comm_get_unique_id", "rvo_comm_create", "rvo_comm_destroy", "rvo_gather_trajectories",
+    "rvo_set_pipeline", "rvo_get_batch_results", "rvo_comm_get_unique_id", "rvo_comm_create", "rvo_comm_destroy", "rvo_gather_trajectories",
 ]
 TRAJ_DOUBLES = 16   # RVO_TRAJ_DOUBLES
 COMM_ID_BYTES = 128  # RVO_COMM_ID_BYTES
@@ -136,6 +136,8 @@ def load():
     L.rvo_profile_select.argtypes = [vp, C.c_char_p]
     L.rvo_profile_read.argtypes = [vp, ip, vp, vp, vp]
     L.rvo_selftest_stdalgo.argtypes = [ip, vp, ip, ip, ip, vp]
+    L.rvo_set_pipeline.argtypes = [vp, ip]
+    L.rvo_get_batch_results.argtypes = [vp, ip, ip, vp]
     L.rvo_streams_record.argtypes = [vp, ip]
     L.rvo_trajectories_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rvo_get_trajectories.argtypes = [vp, ip, ip, vp]

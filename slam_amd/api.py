@@ -151,6 +151,10 @@ class Context:
     def set_pair_chunks(self, chunks: int):
         self._chk(self.L.rvo_set_pair_chunks(self.h, chunks))
 
+    def set_pipeline(self, staged: bool):
+        """rvo_set_pipeline: staged = consecutive match_frames_dev calls overlap inside this context (stage per stream)."""
+        self._chk(self.L.rvo_set_pipeline(self.h, 1 if staged else 0))
+
     def wait_peer(self, peer: "Context"):
         """What is enqueued next waits until the FAST stage of peer's batch in flight is done (rvo_wait_peer)."""
         self._chk(self.L.rvo_wait_peer(self.h, peer.h))
@@ -345,38 +349,63 @@ class FrameMatcher:
 
 
 class PipelinedFrameMatcher:
-    """Batches of FrameMatcher::Match (fm.cpp:32-58) kept in flight on `depth` contexts that take alternate batches
-    (double buffering): the one-workgroup-per-pair stages of one batch (clique, Gauss-Newton, initial rotation) overlap
-    the image stages of the next.  Each submit() is ONE rvo_match_frames_dev call; nothing is synchronised until
-    results() / sync().  Inputs are device pointers and are read in place (see include/rvo.h)."""
+    """Batches of FrameMatcher::Match (fm.cpp:32-58) kept in flight.  Each submit() is ONE rvo_match_frames_dev call;
+    nothing is synchronised until results() / sync().  Inputs are device pointers and are read in place (include/rvo.h).
 
-    def __init__(self, intr: dict, n_pairs: int, params: Params | None = None, device: int = 0, depth: int = 2):
+    contexts = 1 (default): the library's staged pipeline (rvo_set_pipeline) -- one context, whose four streams run the
+    frame stages of batch k+1 beside the pair stages and the latency-bound tail (clique, Gauss-Newton) of batch k;
+    consecutive batches rotate through three sets of frame slots (a batch's frames are read by its pair stages while
+    the next batch's frames are being prepared).
+    contexts >= 2: the round-1 arrangement -- `contexts` contexts take alternate batches, each as one chain
+    (double buffering by the caller), with rvo_wait_peer before every submit."""
+
+    def __init__(self, intr: dict, n_pairs: int, params: Params | None = None, device: int = 0, depth: int | None = None,
+                 contexts: int = 1):
+        if depth is not None:  # the old keyword: number of contexts taking alternate batches
+            contexts = depth
         self.n_pairs = n_pairs
         p = params or default_params(frame_matcher=True)
-        self.ctxs = [Context(intr, p, max_frames=2 * n_pairs, max_pairs=n_pairs, device=device) for _ in range(depth)]
-        if depth > 1:
+        self.staged = contexts == 1
+        if self.staged:
+            nsets = int(os.environ.get("RVO_SLOT_SETS", "3"))  # frame-slot sets consecutive batches rotate through
+            self.ctxs = [Context(intr, p, max_frames=2 * nsets * n_pairs, max_pairs=n_pairs, device=device)]
+            self.ctxs[0].set_pipeline(True)
+            self.slot_sets = [np.arange(2 * n_pairs * i, 2 * n_pairs * (i + 1), dtype=np.int32) for i in range(nsets)]
+        else:
+            self.ctxs = [Context(intr, p, max_frames=2 * n_pairs, max_pairs=n_pairs, device=device) for _ in range(contexts)]
             for c in self.ctxs:
+                c.set_pipeline(False)
                 c.set_pair_chunks(1)
-        self.slots = np.arange(2 * n_pairs, dtype=np.int32)
+            self.slot_sets = [np.arange(2 * n_pairs, dtype=np.int32)]
         self.k = 0
         self.stagger = os.environ.get("RVO_STAGGER", "1") != "0"  # rvo_wait_peer before every submit (+2 %)
+
+    def slots_of(self, ticket: int) -> np.ndarray:
+        """Frame slots batch `ticket` was prepared into (frames 2i, 2i+1 -> pair i)."""
+        return self.slot_sets[ticket % len(self.slot_sets)]
 
     def submit(self, gray_ptr: int, depth_ptr: int, fast_thr, init_pose=None) -> int:
         """Enqueue one batch (frames 2i, 2i+1 -> pair i).  Returns the ticket results() takes."""
         c = self.ctxs[self.k % len(self.ctxs)]
-        if self.stagger and len(self.ctxs) > 1:
+        if not self.staged and self.stagger and len(self.ctxs) > 1:
             c.wait_peer(self.ctxs[(self.k - 1) % len(self.ctxs)])
-        c.match_frames_dev(gray_ptr, depth_ptr, fast_thr, self.slots, init_pose)
+        c.match_frames_dev(gray_ptr, depth_ptr, fast_thr, self.slots_of(self.k), init_pose)
         self.k += 1
         return self.k - 1
 
     def context_of(self, ticket: int) -> Context:
-        if not (self.k - len(self.ctxs) <= ticket < self.k):
+        keep = 2 if self.staged else len(self.ctxs)
+        if not (self.k - keep <= ticket < self.k):
             raise ValueError("the results of that batch have been overwritten by a later one")
         return self.ctxs[ticket % len(self.ctxs)]
 
     def results(self, ticket: int):
-        return self.context_of(ticket).pair_results(self.n_pairs)
+        c = self.context_of(ticket)
+        if not self.staged:
+            return c.pair_results(self.n_pairs)
+        out = (PairResult * self.n_pairs)()
+        c._chk(c.L.rvo_get_batch_results(c.h, self.k - 1 - ticket, self.n_pairs, out))
+        return [pair_result_to_dict(r) for r in out]
 
     def sync(self):
         for c in self.ctxs:

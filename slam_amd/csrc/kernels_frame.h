@@ -128,7 +128,11 @@ __device__ inline int gauss_tap(F at, int n, int r) {
 // four at a time on u16 pairs packed in 32-bit registers (a tap sum is at most 16*255, so plain integer adds and
 // multiplies never carry between the halves); the first/last output of a line takes the reference's edge formulas
 // through gauss_tap.
-__global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots, int lvl) {
+// gray_inplace / depth_inplace (rvo_match_frames_dev, lvl == 1 only, else null): the batch's images, read where they
+// lie; the launch then also records them as the slots' level-0 / depth images (what k_ingest would do in a launch of
+// its own), for the kernels that follow on the stream.
+__global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots, int lvl,
+                                                  const uint8_t* __restrict__ gray_inplace, const uint16_t* __restrict__ depth_inplace) {
   RVO_OCC_SCOPE(1, 16);
   const LevelGeom S = g.lv[lvl - 1], D = g.lv[lvl];
   int tile, fi;  // XCD-aware: the tiles of a frame share source lines
@@ -136,7 +140,11 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
   const int tile_y = tile / (int)gridDim.x, tile_x = tile - tile_y * (int)gridDim.x;
   const int slot = slots[fi];
   if (slot < 0) return;  // stream still in warm-up (vo.cpp:58-69)
-  const uint8_t* __restrict__ src = level_img(fb, g, slot, lvl - 1);
+  const uint8_t* __restrict__ src = gray_inplace ? gray_inplace + (size_t)fi * g.W * g.H : level_img(fb, g, slot, lvl - 1);
+  if (gray_inplace && tile == 0 && threadIdx.x == 0) {
+    fb.l0_tab[slot] = src;
+    fb.depth_tab[slot] = depth_inplace + (size_t)fi * g.Wd * g.Hd;
+  }
   uint8_t* __restrict__ dst = fb.img + (size_t)slot * g.img_bytes + D.img_off;
   const int dw = S.w / 2, dh = S.h / 2;
   const int ox0 = tile_x * PYR_TW, oy0 = tile_y * PYR_TH;
@@ -782,26 +790,14 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
     base += total;
   }
   if (tid == 0) fb.kp_cnt[slot * RVO_MAX_LEVELS + lvl] = base;
-}
-
-// Descriptors of the keypoints that survived the border / LUT / depth filter: their rows of bk_desc (written by
-// k_fast_grid) are copied into the level's compact order.  grid (ceil(kp_total*5/256), n_frames): one 16-byte piece
-// per thread, five consecutive threads per keypoint.  Runs after k_build_keypoints (reads kp_src / kp_cnt).
-__global__ __launch_bounds__(256) void k_descriptors(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots) {
-  RVO_OCC_SCOPE(4, 16);
-  const int slot = slots[blockIdx.y];
-  if (slot < 0) return;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int idx = t / 5, piece = t - idx * 5;  // keypoint slot within the frame
-  if (idx >= g.kp_total) return;
-  int lvl = 0;
-#pragma unroll
-  for (int l = 1; l < RVO_MAX_LEVELS; l++)
-    if (l < g.levels && idx >= g.lv[l].kp_off) lvl = l;
-  const int koff = g.lv[lvl].kp_off;
-  if (idx - koff >= fb.kp_cnt[slot * RVO_MAX_LEVELS + lvl]) return;
-  const size_t kbase = (size_t)slot * g.kp_total;
-  const size_t src = kbase + koff + fb.kp_src[kbase + idx];
-  reinterpret_cast<uint4*>(fb.kp_desc + (kbase + idx) * RVO_DESC_LEN)[piece] =
-      reinterpret_cast<const uint4*>(fb.bk_desc + src * RVO_DESC_LEN)[piece];
+  // Descriptors of the keypoints that survived: their rows of bk_desc (written by k_fast_grid) are copied into the
+  // level's compact order, one 16-byte piece per thread and trip, five consecutive threads per keypoint.  (Was a kernel
+  // of its own; here it costs no launch.)  The kp_src entries were written by other threads of this workgroup.
+  __syncthreads();
+  for (int t = tid; t < base * 5; t += 256) {
+    const int idx = t / 5, piece = t - idx * 5;
+    const size_t src = kbase + fb.kp_src[kbase + idx];
+    reinterpret_cast<uint4*>(fb.kp_desc + (kbase + idx) * RVO_DESC_LEN)[piece] =
+        reinterpret_cast<const uint4*>(fb.bk_desc + src * RVO_DESC_LEN)[piece];
+  }
 }

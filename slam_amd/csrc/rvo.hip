@@ -86,6 +86,19 @@ struct rvo_ctx {
   bool rot_side = true;  // k_init_rotation on a side stream (env RVO_ROT_SIDE=0: on the batch's own stream)
   hipEvent_t ev_mid = nullptr;  // recorded after k_fast_grid of a batch (rvo_wait_peer)
   int pair_chunks = 2;
+  // Staged pipeline of rvo_match_frames_dev: the stages of successive batches run on four streams
+  // -- frames (the context's stream), initial rotation, pair stages, tail (clique + Gauss-Newton) -- so that the
+  // latency-bound tail of batch k runs beside the frame stages of batch k+1 and the pair stages of ... without ever
+  // holding up the next submit.  Pair work areas exist twice (pbs[0], pbs[1]); `pb` is the set of the latest batch.
+  bool staged = true;            // env RVO_STAGED=0 / rvo_set_pipeline(ctx, 0): the chunked single-chain form
+  PairBufs pbs[2];
+  long long batch_id = 0;        // staged batches submitted so far
+  int staged_pending = 0;        // bit s: set s has staged work the main stream has not been ordered after yet
+  hipEvent_t ev_f[2] = {}, ev_p[2] = {}, ev_t[2] = {}, ev_up[2] = {}, ev_pyr2[2] = {}, ev_rot2[2] = {};
+  bool ev_p_rec[2] = {false, false}, ev_t_rec[2] = {false, false};
+  static const int kSlotRing = 4;  // pair-stage completion events of the last four staged batches (frame slot reuse)
+  hipEvent_t ev_pdone[kSlotRing] = {};
+  std::vector<long long> slot_reader;  // [max_frames] last staged batch whose pair stages read the slot (-1: none)
   // profiling
   bool prof = false;
   std::string prof_only;  // rvo_profile_select: bracket only launches of this kernel ("" = all)
@@ -107,8 +120,9 @@ static int dalloc(rvo_ctx* c, T** p, size_t n) {
 
 // Stream-ordered H2D copy of a small argument array through pinned memory; never blocks on prior GPU work
 // (a pageable hipMemcpyAsync may) and never lets the host buffer be reused while a copy is pending.
-static int stage_args(rvo_ctx* c, void* dst_dev, const void* src, size_t bytes) {
+static int stage_args(rvo_ctx* c, void* dst_dev, const void* src, size_t bytes, hipStream_t st = nullptr) {
   if (bytes == 0) return 0;
+  if (!st) st = c->stream;
   if (bytes > c->ring_bytes) { g_err = "stage_args: argument array larger than the staging region"; return RVO_E_INVALID; }
   const int r = c->ring_pos;
   c->ring_pos = (r + 1) % rvo_ctx::kRing;
@@ -116,8 +130,8 @@ static int stage_args(rvo_ctx* c, void* dst_dev, const void* src, size_t bytes) 
   if (e != hipSuccess) { g_err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); return RVO_E_HIP; }
   uint8_t* h = c->h_ring + (size_t)r * c->ring_bytes;
   memcpy(h, src, bytes);
-  e = hipMemcpyAsync(dst_dev, h, bytes, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipEventRecord(c->ring_ev[r], c->stream);
+  e = hipMemcpyAsync(dst_dev, h, bytes, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipEventRecord(c->ring_ev[r], st);
   if (e != hipSuccess) { g_err = std::string("stage_args: ") + hipGetErrorString(e); return RVO_E_HIP; }
   return 0;
 }
@@ -171,8 +185,14 @@ static int scratch_for_device(int device) {
   return RVO_OK;
 }
 
+#ifdef RVO_SKIP_EXPERIMENT  // one-off builds: RVO_SKIP=<kernel name> drops that launch (what does it cost the pipeline?)
+#define RVO_SKIPPED(NAME) (getenv("RVO_SKIP") && strcmp(getenv("RVO_SKIP"), NAME) == 0)
+#else
+#define RVO_SKIPPED(NAME) false
+#endif
 #define LAUNCH_ON(c, STREAM, NAME, KERNEL, GRID, BLOCK, SHMEM, ...)                       \
   do {                                                                                    \
+    if (RVO_SKIPPED(NAME)) break;                                                         \
     ProfRec pr_;                                                                          \
     const bool prof_ = (c)->prof && ((c)->prof_only.empty() || (c)->prof_only == NAME);   \
     if (prof_) {                                                                          \
@@ -320,12 +340,38 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
   c->ring_bytes = std::max<size_t>(4096, (size_t)std::max(max_frames, max_pairs) * 12 * 8);
   HIPCHK(hipHostMalloc((void**)&c->h_ring, c->ring_bytes * rvo_ctx::kRing, hipHostMallocDefault));
   for (int i = 0; i < rvo_ctx::kRing; i++) HIPCHK(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
-  HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  // HIP multiplexes the streams of one priority onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and streams that
+  // share a queue run in submission order (measured: tools/native/queue_probe.hip); every priority has a pool of its
+  // own.  All four streams of a context are created at the greatest priority: the pool they share with nothing else in
+  // a typical process (torch's streams are at the normal priority), so the staged pipeline's streams do not alias.
+  // They must all have the SAME priority: with the frame stages at normal and the tail at high priority, a context
+  // stopped making progress as soon as two more processes used the GPU (its high-priority queues, blocked on events
+  // of the normal ones, kept those from being scheduled; tools/exp_three_procs.py).
+  // RVO_STREAM_PRIORITY = one letter per stream (own, aux0, aux1, aux2; h greatest, n normal, l least): experiments.
+  const char* prio_env = getenv("RVO_STREAM_PRIORITY");
+  const char* prio = (prio_env && strlen(prio_env) == 1 + rvo_ctx::kAux) ? prio_env : "hhhh";
+  int least = 0, greatest = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  auto prio_of = [&](char ch) { return ch == 'h' ? greatest : ch == 'l' ? least : 0; };
+  HIPCHK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, prio_of(prio[0])));
   c->stream = c->own_stream;
-  for (int i = 0; i < rvo_ctx::kAux; i++) {
-    HIPCHK(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+  {
+    for (int i = 0; i < rvo_ctx::kAux; i++) {
+      HIPCHK(hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio_of(prio[1 + i])));
+      HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
   }
+  for (int i = 0; i < 2; i++) {
+    HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_t[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_pyr2[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_rot2[i], hipEventDisableTiming));
+  }
+  for (int i = 0; i < rvo_ctx::kSlotRing; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_pdone[i], hipEventDisableTiming));
+  if (const char* e = getenv("RVO_STAGED")) c->staged = atoi(e) != 0;
+  c->slot_reader.assign((size_t)max_frames, -1);
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
   if (const char* e = getenv("RVO_ROT_SIDE")) c->rot_side = atoi(e) != 0;
@@ -398,6 +444,11 @@ void rvo_destroy(rvo_ctx* c) {
     if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
   }
+  for (int i = 0; i < 2; i++) {
+    hipEvent_t* evs[6] = {&c->ev_f[i], &c->ev_p[i], &c->ev_t[i], &c->ev_up[i], &c->ev_pyr2[i], &c->ev_rot2[i]};
+    for (auto e : evs) if (*e) (void)hipEventDestroy(*e);
+  }
+  for (int i = 0; i < rvo_ctx::kSlotRing; i++) if (c->ev_pdone[i]) (void)hipEventDestroy(c->ev_pdone[i]);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   for (int i = 0; i < 2; i++) {
@@ -408,8 +459,39 @@ void rvo_destroy(rvo_ctx* c) {
   delete c;
 }
 
+// Orders the context's main stream after every staged batch still in flight (their pair and tail stages run on other
+// streams): called by every entry point that touches pair work areas or frame slots outside the staged pipeline.
+static int join_staged(rvo_ctx* c) {
+  for (int s = 0; s < 2; s++) {
+    if (!(c->staged_pending & (1 << s))) continue;
+    if (c->ev_p_rec[s]) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_p[s], 0));
+    if (c->ev_t_rec[s]) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_t[s], 0));
+  }
+  c->staged_pending = 0;
+  return RVO_OK;
+}
+// waits for everything the context has enqueued on any of its streams
+#define SYNC_MAIN(c)                                                  \
+  do {                                                                \
+    const int rcj_ = join_staged(c);                                  \
+    if (rcj_) return rcj_;                                            \
+    HIPCHK(hipStreamSynchronize((c)->stream));                        \
+  } while (0)
+// Frame slots about to be rewritten on stream st: wait for the pair stages of the staged batches that still read them.
+static int wait_slots_free(rvo_ctx* c, hipStream_t st, int n, const int32_t* slots) {
+  long long need = -1;
+  for (int i = 0; i < n; i++) need = std::max(need, c->slot_reader[slots[i]]);
+  if (need < 0) return RVO_OK;
+  // events exist for the last kSlotRing batches; an older batch's pair stages precede theirs on the pair stream
+  const long long b = std::max(need, c->batch_id - rvo_ctx::kSlotRing);
+  if (b >= 0 && b < c->batch_id) HIPCHK(hipStreamWaitEvent(st, c->ev_pdone[b % rvo_ctx::kSlotRing], 0));
+  return RVO_OK;
+}
+
 int rvo_set_stream(rvo_ctx* c, void* s) {
   if (!c) return RVO_E_INVALID;
+  { const int rc0 = join_staged(c); if (rc0) return rc0; }
+  if (s) c->staged = false;  // work on a caller's stream runs as one chain per call (see rvo_set_pipeline)
   c->stream = s ? (hipStream_t)s : c->own_stream;
   return RVO_OK;
 }
@@ -422,14 +504,27 @@ int rvo_set_pair_chunks(rvo_ctx* c, int chunks) {
 
 int rvo_sync(rvo_ctx* c) {
   if (!c) return RVO_E_INVALID;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC_MAIN(c);
+  return RVO_OK;
+}
+
+int rvo_set_pipeline(rvo_ctx* c, int staged) {
+  if (!c) return RVO_E_INVALID;
+  if (staged && c->stream != c->own_stream) {
+    // the stages wait on each other across streams: a caller's stream of another priority would bring back the
+    // priority inversion described in ctx_init
+    g_err = "rvo_set_pipeline: the staged pipeline runs on the context's own streams (rvo_set_stream(ctx, NULL) first)";
+    return RVO_E_UNSUPPORTED;
+  }
+  { const int rc0 = join_staged(c); if (rc0) return rc0; }
+  c->staged = staged != 0;
   return RVO_OK;
 }
 
 static int ensure_stage(rvo_ctx* c, int n) {
   const FrameGeom& g = c->g;
   if (c->stage_frames >= (size_t)n) return RVO_OK;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC_MAIN(c);
   if (c->d_gray_stage) (void)hipFree(c->d_gray_stage);
   if (c->d_depth_stage) (void)hipFree(c->d_depth_stage);
   c->d_gray_stage = nullptr; c->d_depth_stage = nullptr; c->stage_frames = 0;
@@ -458,14 +553,22 @@ static int launch_ingest(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t*
 
 // ---------------------------------------------------------------- PrepareFrame
 // enqueue the frame kernels on stream `st` for n frames whose slots/thresholds are at d_slots/d_thr (device)
-static int enqueue_pyramid_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots) {
+// gray / depth non-null: the images are read in place (see can_read_in_place) and the first launch records them as the
+// slots' level-0 / depth images.
+static int enqueue_pyramid_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots, const uint8_t* gray = nullptr,
+                              const uint16_t* depth = nullptr) {
   const FrameGeom& g = c->g;
   for (int l = 1; l < g.levels; l++) {
     const int dw = g.lv[l - 1].w / 2, dh = g.lv[l - 1].h / 2;
     dim3 grid((dw + PYR_TW - 1) / PYR_TW, (dh + PYR_TH - 1) / PYR_TH, n);
-    LAUNCH_ON(c, st, "pyr_down", k_pyr_down, grid, dim3(256), 0, c->fb, g, d_slots, l);
+    LAUNCH_ON(c, st, "pyr_down", k_pyr_down, grid, dim3(256), 0, c->fb, g, d_slots, l, l == 1 ? gray : nullptr, l == 1 ? depth : nullptr);
   }
   return RVO_OK;
+}
+// rvo_match_frames_dev: level 0 needs no copy when the caller's rows already have the level-0 stride and 16-byte
+// alignment; with at least two pyramid levels the first k_pyr_down launch then does k_ingest's bookkeeping as well.
+static bool can_read_in_place(const rvo_ctx* c, const uint8_t* gray) {
+  return c->g.levels >= 2 && c->g.lv[0].stride == c->g.W && ((uintptr_t)gray & 15) == 0;
 }
 static int enqueue_features_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots, const int32_t* d_thr) {
   const FrameGeom& g = c->g;
@@ -475,7 +578,6 @@ static int enqueue_features_on(rvo_ctx* c, hipStream_t st, int n, const int32_t*
     LAUNCH_ON(c, st, "fast_grid", (k_fast_grid<0, 0>), dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
   if (st == c->stream) HIPCHK(hipEventRecord(c->ev_mid, st));  // rvo_wait_peer
   LAUNCH_ON(c, st, "build_keypoints", k_build_keypoints, dim3(g.levels, n), dim3(256), 0, c->fb, g, d_slots);
-  LAUNCH_ON(c, st, "descriptors", k_descriptors, dim3((g.kp_total * 5 + 255) / 256, n), dim3(256), 0, c->fb, g, d_slots);
   HIPCHK(hipGetLastError());
   return RVO_OK;
 }
@@ -505,6 +607,7 @@ int rvo_prepare_frames_dev(rvo_ctx* c, int n, const uint8_t* gray, const uint16_
   for (int i = 0; i < n; i++)
     if (thr[i] < 0 || thr[i] > 255) { g_err = "rvo_prepare_frames: FAST threshold outside 0..255"; return RVO_E_INVALID; }
   HIPCHK(hipSetDevice(c->device));
+  { const int rc0 = wait_slots_free(c, c->stream, n, slots); if (rc0) return rc0; }
   std::vector<int32_t> args(2 * (size_t)n);
   memcpy(args.data(), slots, n * 4);
   memcpy(args.data() + n, thr, n * 4);
@@ -523,7 +626,7 @@ int rvo_prepare_frames(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* d
   HIPCHK(hipMemcpyAsync(c->d_depth_stage, depth, (size_t)n * g.Wd * g.Hd * 2, hipMemcpyHostToDevice, c->stream));
   int rc = rvo_prepare_frames_dev(c, n, c->d_gray_stage, c->d_depth_stage, thr, slots);
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC_MAIN(c);
   return RVO_OK;
 }
 
@@ -535,7 +638,7 @@ static int check_slot_level(rvo_ctx* c, int slot, int level) {
 
 int rvo_get_level_info(rvo_ctx* c, int slot, int level, int32_t* info) {
   if (check_slot_level(c, slot, level) || !info) return RVO_E_INVALID;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC_MAIN(c);
   const LevelGeom& L = c->g.lv[level];
   int32_t v[3];
   HIPCHK(hipMemcpy(&v[0], c->fb.kp_cnt + slot * RVO_MAX_LEVELS + level, 4, hipMemcpyDeviceToHost));
@@ -547,7 +650,7 @@ int rvo_get_level_info(rvo_ctx* c, int slot, int level, int32_t* info) {
 
 int rvo_get_level_image(rvo_ctx* c, int slot, int level, uint8_t* out) {
   if (check_slot_level(c, slot, level) || !out) return RVO_E_INVALID;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC_MAIN(c);
   const LevelGeom& L = c->g.lv[level];
   const uint8_t* src = c->fb.img + (size_t)slot * c->g.img_bytes + L.img_off;
   if (level == 0) HIPCHK(hipMemcpy(&src, c->fb.l0_tab + slot, sizeof(src), hipMemcpyDeviceToHost));  // may live in caller memory
@@ -557,7 +660,7 @@ int rvo_get_level_image(rvo_ctx* c, int slot, int level, uint8_t* out) {
 
 int rvo_get_grid_keypoints(rvo_ctx* c, int slot, int level, float* uvs) {
   if (check_slot_level(c, slot, level) || !uvs) return RVO_E_INVALID;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC_MAIN(c);
   const FrameGeom& g = c->g;
   const LevelGeom& L = g.lv[level];
   std::vector<int32_t> cnt(L.nbuckets);
@@ -575,7 +678,7 @@ int rvo_get_grid_keypoints(rvo_ctx* c, int slot, int level, float* uvs) {
 
 int rvo_get_keypoints(rvo_ctx* c, int slot, int level, float* uvs, double* rect, double* xyz) {
   if (check_slot_level(c, slot, level)) return RVO_E_INVALID;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC_MAIN(c);
   const FrameGeom& g = c->g;
   const LevelGeom& L = g.lv[level];
   int32_t n = 0;
@@ -595,7 +698,7 @@ int rvo_get_keypoints(rvo_ctx* c, int slot, int level, float* uvs, double* rect,
 
 int rvo_get_descriptors(rvo_ctx* c, int slot, int level, uint8_t* out) {
   if (check_slot_level(c, slot, level) || !out) return RVO_E_INVALID;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC_MAIN(c);
   const FrameGeom& g = c->g;
   int32_t n = 0;
   HIPCHK(hipMemcpy(&n, c->fb.kp_cnt + slot * RVO_MAX_LEVELS + level, 4, hipMemcpyDeviceToHost));
@@ -613,7 +716,7 @@ int rvo_get_lut(rvo_ctx* c, float* xmap, float* ymap) {
 
 int rvo_profile_enable(rvo_ctx* c, int on) {
   if (!c) return RVO_E_INVALID;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC_MAIN(c);
   prof_drain(c);
   c->prof_acc.clear();
   c->prof = on != 0;
@@ -628,7 +731,7 @@ int rvo_profile_select(rvo_ctx* c, const char* kernel_name) {
 
 int rvo_profile_read(rvo_ctx* c, int cap, const char** names, float* total_ms, int32_t* calls) {
   if (!c) return RVO_E_INVALID;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC_MAIN(c);
   prof_drain(c);
   int n = 0;
   for (auto& kv : c->prof_acc) {
@@ -652,9 +755,10 @@ extern "C" int rvo_get_pair_information_noalloc(rvo_ctx* c, int n, double* info)
   double* sp = (c->device >= 0 && c->device < kMaxDevices) ? g_scratch_ptr[c->device] : nullptr;  // resolved by rvo_create on this device
   if (!sp) { g_err = "rvo_get_pair_information_noalloc: no static staging area on this device"; return RVO_E_UNSUPPORTED; }
   HIPCHK(hipSetDevice(c->device));
+  { const int rc0 = join_staged(c); if (rc0) return rc0; }
   hipLaunchKernelGGL(k_pair_information, dim3((n + 63) / 64), dim3(64), 0, c->stream, c->pb, n, sp);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(info, sp, (size_t)n * 36 * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC_MAIN(c);
   return RVO_OK;
 }

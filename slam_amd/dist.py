@@ -161,7 +161,15 @@ def gather_trajectories_auto(local: np.ndarray, device_index: int, timeout_s: fl
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     equal = len({int(x.item()) for x in sizes}) == 1
-    if equal and not HUNG:
+    # one node, one rank per GPU: RCCL refuses two ranks on one device (after a slow failed bootstrap), so a rehearsal in
+    # which ranks share a card goes straight to gloo
+    d = torch.tensor([device_index], dtype=torch.int64)
+    devs = [torch.zeros_like(d) for _ in range(world)]
+    dist.all_gather(devs, d)
+    distinct = len({int(x.item()) for x in devs}) == world
+    if not distinct:
+        notes.append("ranks share a GPU: RCCL not attempted")
+    if equal and distinct and not HUNG:
         state = {}
 
         def attempt():
@@ -193,7 +201,7 @@ def gather_trajectories_auto(local: np.ndarray, device_index: int, timeout_s: fl
         has_nccl = "nccl" in str(dist.get_backend_config())
     except Exception:  # noqa: BLE001
         pass
-    if has_nccl and not HUNG:
+    if has_nccl and distinct and not HUNG:
         t1 = time.perf_counter()
         try:
             out = _with_timeout(lambda: gather_trajectories(local, torch.device("cuda", device_index)), timeout_s)

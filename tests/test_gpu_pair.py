@@ -227,3 +227,59 @@ def test_batches_in_flight_on_two_contexts_are_independent_and_deterministic(sce
         ctxs[0].match_frames_dev(batches[0][0].data_ptr(), batches[0][1].data_ptr(), 300, slots)
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("slot_sets", [3, 1])
+def test_staged_pipeline_in_one_context_equals_a_context_working_alone(scene, intr640, slot_sets, monkeypatch):
+    """rvo_set_pipeline(1): one context keeps the frame stages of batch k+1, the pair stages of batch k and the tail of
+    batch k-1 on its four streams.  Every batch must give the bits of a context that runs it alone as one chain; with a
+    single set of frame slots (slot_sets = 1) the library itself has to hold batch k+1's frame stages back until batch
+    k's pair stages have read the slots.  rvo_get_batch_results reaches the last two batches; rvo_get_matches the last."""
+    import torch
+    from slam_amd.api import Context, PipelinedFrameMatcher, default_params
+    monkeypatch.setenv("RVO_SLOT_SETS", str(slot_sets))
+    n = 40
+    pairs = [synth.make_pair(700 + i, intr640, scene, invalid_frac=0.1 * (i % 2)) for i in range(5)]
+    batches = []
+    for shift in range(3):  # three different batches
+        gray = np.stack([pairs[(i + shift) % 5][j] for i in range(n) for j in (0, 2)])
+        depth = np.stack([pairs[(i + shift) % 5][j] for i in range(n) for j in (1, 3)])
+        batches.append((torch.from_numpy(gray).cuda(), torch.from_numpy(depth.view(np.int16)).cuda()))
+    torch.cuda.synchronize()
+    slots = np.arange(2 * n, dtype=np.int32)
+
+    def key(res):
+        return [(r["status"], r["num_matches"], r["num_inliers"], r["pose"].tobytes(), r["cov"].tobytes()) for r in res]
+
+    alone, alone_matches = [], []
+    for dg, dd in batches:
+        c = Context(intr640, default_params(frame_matcher=True), max_frames=2 * n, max_pairs=n)
+        c.set_pipeline(False)
+        c.match_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, slots)
+        res = c.pair_results(n)
+        alone.append(key(res))
+        alone_matches.append(c.matches(n - 1, res[n - 1]["num_matches"]))
+        c.close()
+    pipe = PipelinedFrameMatcher(intr640, n, contexts=1)
+    assert len(pipe.slot_sets) == slot_sets
+    tickets = [pipe.submit(*[t.data_ptr() for t in batches[k % 3]], 20) for k in range(8)]
+    assert key(pipe.results(tickets[-2])) == alone[6 % 3]  # while batch 7 may still be running
+    assert key(pipe.results(tickets[-1])) == alone[7 % 3]
+    with pytest.raises(ValueError):
+        pipe.results(tickets[-3])  # overwritten by batch 7
+    ctx = pipe.ctxs[0]
+    im, dm = ctx.matches(n - 1, alone[7 % 3][n - 1][1])
+    assert np.array_equal(im, alone_matches[7 % 3][0]) and np.array_equal(dm, alone_matches[7 % 3][1], equal_nan=True)
+    # given initial poses (no EstimateInitialRotation on the R stream), then back to one chain per call in the same context
+    res_alone = None
+    init = np.tile(np.eye(4)[:3].reshape(1, 12), (n, 1))
+    for k in range(3):
+        t = pipe.submit(*[x.data_ptr() for x in batches[k]], 20, init)
+    staged_init = key(pipe.results(t))
+    ctx.set_pipeline(False)
+    ctx.match_frames_dev(batches[2][0].data_ptr(), batches[2][1].data_ptr(), 20, slots, init)
+    res_alone = key(ctx.pair_results(n))
+    assert staged_init == res_alone
+    ctx.match_frames_dev(batches[1][0].data_ptr(), batches[1][1].data_ptr(), 20, slots)
+    assert key(ctx.pair_results(n)) == alone[1]
+    pipe.close()

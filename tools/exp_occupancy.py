@@ -20,7 +20,7 @@ from slam_amd.api import PipelinedFrameMatcher
 n_pairs = 256
 gray, depth, _ = bench.make_batch(n_pairs, 0)
 dg = torch.from_numpy(gray).cuda(); dd = torch.from_numpy(depth.view(np.int16)).cuda()
-pipe = PipelinedFrameMatcher(synth.default_intrinsics(640, 480), n_pairs, depth=nctx)
+pipe = PipelinedFrameMatcher(synth.default_intrinsics(640, 480), n_pairs, contexts=nctx)
 torch.cuda.synchronize()
 L = _lib.load()
 for k in range(6):
