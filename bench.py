@@ -57,11 +57,10 @@ def algorithmic_bytes(geom: dict, stats: dict) -> dict:
     lv = [(W >> l) * (H >> l) for l in range(L)]
     K, N = stats["mean_kp_per_frame"], stats["mean_matches"]
     B = {}
-    B["ingest"] = nf * 16  # rvo_match_frames_dev reads gray and depth in place: the launch records two pointers per slot
     B["pyr_down"] = nf * sum(lv[l - 1] + lv[l] for l in range(1, L)) / max(1, L - 1)
     B["fast_grid"] = nf * (sum(lv) + geom["total_buckets"] * (geom["max_per"] * (4 + 80) + 8))
-    B["build_keypoints"] = nf * (geom["total_buckets"] * (geom["max_per"] * 4 + 8) + K * (36 + 8 + 4 + 2 + 8))
-    B["descriptors"] = nf * K * (2 + 80 + 80)
+    # bucket lists in, keypoint records out, and the descriptor rows moved from bucket order to keypoint order (80 B each way)
+    B["build_keypoints"] = nf * (geom["total_buckets"] * (geom["max_per"] * 4 + 8) + K * (36 + 8 + 4 + 2 + 8) + K * (2 + 80 + 80))
     B["init_rotation"] = npair * 2 * lv[L - 1]
     B["match"] = npair * (2 * K * 80 + 2 * K * 32 + N * 8)
     B["refine"] = npair * N * (2 * 100 + 20)
@@ -81,6 +80,8 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="passes over those pairs (about 10 s of CPU work in all)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--prewarm", type=float, default=float(os.environ.get("RVO_BENCH_PREWARM_S", "1.0")),
+                    help="seconds of untimed work before the warm-up steps (clocks of an idle box)")
     a = ap.parse_args()
 
     # `python bench.py --gpus N` without an outer launcher: start the N rank processes ourselves (one per GPU) and relay
@@ -165,7 +166,7 @@ def main():
     noprof = bool(os.environ.get("RVO_BENCH_NOPROF"))
     # A box that has been idle runs its first ~0.5 s of work at lower clocks (first run after a lease: 230k instead of
     # 290k pairs/s with 10 warm-up steps = 9 ms): keep the GPU busy for a second before the W warm-up steps.  Untimed.
-    prewarm_s = float(os.environ.get("RVO_BENCH_PREWARM_S", "1.0"))
+    prewarm_s = a.prewarm
     t_pw = time.perf_counter()
     while time.perf_counter() - t_pw < prewarm_s:
         for k in range(8):
@@ -264,14 +265,14 @@ def main():
             avg_s = prof_dom[dom]["total_ms"] / prof_dom[dom]["calls"] * 1e-3
             ach = B[dom] / avg_s
             # HBM traffic per launch: not measurable from inside this process; taken from the committed rocprofv3
-            # --pmc passes of this same command (profiles/r01_pmc_traffic.json), valid for the default launch shape
+            # --pmc passes of this same command (profiles/r02_pmc_traffic.json), valid for the default launch shape
             traffic, traffic_src = None, None
-            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
             if os.path.exists(tp) and n_pairs == 256 and n_ctx == 1 and not os.environ.get("RVO_PAIR_CHUNKS"):
                 tj = json.load(open(tp))
                 if dom in tj["kernels"]:
                     traffic = tj["kernels"][dom]["traffic_bytes"]
-                    traffic_src = "profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, separate --pmc passes"
+                    traffic_src = "profiles/r02_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, separate --pmc passes"
             roof = dict(bound="hbm", kernel=dom, achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                         frac=ach / HBM_PEAK, traffic=traffic, traffic_source=traffic_src, avg_launch_ms=avg_s * 1e3,
                         launches_timed=prof_dom[dom]["calls"],
@@ -282,12 +283,12 @@ def main():
         # VALU issue roofline (the bound that actually holds for this path): issue time per batch from
         # the committed SQ counters of this same command (a --pmc pass of its own) against the live batch time
         roof_valu = None
-        sp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_sq_counters.csv")
+        sp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_sq_counters.csv")
         if os.path.exists(sp) and n_pairs == 256 and n_ctx == 1 and not os.environ.get("RVO_PAIR_CHUNKS"):
             import csv
             issue_ms = sum(float(r["valu_issue_ms_at_2.4GHz"]) * int(r["launches_per_batch"]) for r in csv.DictReader(open(sp)))
             roof_valu = dict(bound="valu-issue", issue_ms_per_batch=issue_ms, frac=issue_ms / (dt / a.steps * 1e3),
-                             source="profiles/r01_sq_counters.csv: SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz per launch, "
+                             source="profiles/r02_sq_counters.csv: SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz per launch, "
                                     "summed over the launches of one batch")
         kernels = {k: dict(avg_ms=v["total_ms"] / v["calls"], calls=v["calls"],
                            GBps=(B[k] / (v["total_ms"] / v["calls"] * 1e-3) / 1e9) if k in B else None)
