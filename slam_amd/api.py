@@ -353,9 +353,9 @@ class PipelinedFrameMatcher:
     nothing is synchronised until results() / sync().  Inputs are device pointers and are read in place (include/rvo.h).
 
     contexts = 1 (default): the library's staged pipeline (rvo_set_pipeline) -- one context, whose four streams run the
-    frame stages of batch k+1 beside the pair stages and the latency-bound tail (clique, Gauss-Newton) of batch k;
-    consecutive batches rotate through three sets of frame slots (a batch's frames are read by its pair stages while
-    the next batch's frames are being prepared).
+    frame stages of batch k+3 beside the initial rotation + matching of batch k+2, the pair stages of batch k+1 and the
+    latency-bound tail (clique, Gauss-Newton) of batch k; consecutive batches rotate through five sets of frame slots
+    (a batch's frames are read by its pair stages while later batches' frames are being prepared).
     contexts >= 2: the round-1 arrangement -- `contexts` contexts take alternate batches, each as one chain
     (double buffering by the caller), with rvo_wait_peer before every submit."""
 
@@ -367,7 +367,7 @@ class PipelinedFrameMatcher:
         p = params or default_params(frame_matcher=True)
         self.staged = contexts == 1
         if self.staged:
-            nsets = int(os.environ.get("RVO_SLOT_SETS", "3"))  # frame-slot sets consecutive batches rotate through
+            nsets = int(os.environ.get("RVO_SLOT_SETS", "5"))  # frame-slot sets consecutive batches rotate through
             self.ctxs = [Context(intr, p, max_frames=2 * nsets * n_pairs, max_pairs=n_pairs, device=device)]
             self.ctxs[0].set_pipeline(True)
             self.slot_sets = [np.arange(2 * n_pairs * i, 2 * n_pairs * (i + 1), dtype=np.int32) for i in range(nsets)]

@@ -89,14 +89,17 @@ struct rvo_ctx {
   // Staged pipeline of rvo_match_frames_dev: the stages of successive batches run on four streams
   // -- frames (the context's stream), initial rotation, pair stages, tail (clique + Gauss-Newton) -- so that the
   // latency-bound tail of batch k runs beside the frame stages of batch k+1 and the pair stages of ... without ever
-  // holding up the next submit.  Pair work areas exist twice (pbs[0], pbs[1]); `pb` is the set of the latest batch.
+  // holding up the next submit.  Pair work areas exist kPairSets times (the R, P and T stages work on three different
+  // batches at a time, one more set is slack); `pb` is the set of the latest batch.
   bool staged = true;            // env RVO_STAGED=0 / rvo_set_pipeline(ctx, 0): the chunked single-chain form
-  PairBufs pbs[2];
+  static const int kPairSets = 4;
+  int pair_sets = kPairSets;     // env RVO_PAIR_SETS (2..kPairSets): experiments
+  PairBufs pbs[kPairSets];
   long long batch_id = 0;        // staged batches submitted so far
   int staged_pending = 0;        // bit s: set s has staged work the main stream has not been ordered after yet
-  hipEvent_t ev_f[2] = {}, ev_p[2] = {}, ev_t[2] = {}, ev_up[2] = {}, ev_pyr2[2] = {}, ev_rot2[2] = {};
-  bool ev_p_rec[2] = {false, false}, ev_t_rec[2] = {false, false};
-  static const int kSlotRing = 4;  // pair-stage completion events of the last four staged batches (frame slot reuse)
+  hipEvent_t ev_f[kPairSets] = {}, ev_p[kPairSets] = {}, ev_t[kPairSets] = {}, ev_pyr2[kPairSets] = {}, ev_rot2[kPairSets] = {};
+  bool ev_p_rec[kPairSets] = {}, ev_t_rec[kPairSets] = {};
+  static const int kSlotRing = 8;  // pair-stage completion events of the last eight staged batches (frame slot reuse)
   hipEvent_t ev_pdone[kSlotRing] = {};
   std::vector<long long> slot_reader;  // [max_frames] last staged batch whose pair stages read the slot (-1: none)
   // profiling
@@ -330,6 +333,10 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
   fl.cand_cap = std::max(fl.list_cap * 2, ((g.gw + 2) * (g.gh + 2) + 1) / 2);
   fl.off_misc = fl.off_list + round_up(fl.cand_cap * 2, 16);
   fl.total = fl.off_misc + 64 + round_up((g.gw * g.gh + 31) / 32 * 4, 16);
+  if (const char* e = getenv("RVO_FAST_LDS_MIN")) {  // experiments: fewer k_fast_grid workgroups per CU
+    fprintf(stderr, "k_fast_grid LDS %d -> at least %d bytes\n", fl.total, atoi(e));
+    fl.total = std::max(fl.total, round_up(atoi(e), 16));
+  }
   if (fl.total > 150 * 1024 || g.gw + 2 > 255 || g.gh + 2 > 255 || (g.gw + 2) * (g.gh + 2) > 64 * 256 ||
       ((g.gw + 7) / 4 + 1) * (g.gh + 2) > 16 * 256) {  // phase A of k_fast_grid: <= 16 four-pixel groups per thread
     g_err = "grid cell too large for LDS"; return RVO_E_UNSUPPORTED; }
@@ -361,11 +368,10 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
       HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
   }
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < rvo_ctx::kPairSets; i++) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_t[i], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_pyr2[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_rot2[i], hipEventDisableTiming));
   }
@@ -444,8 +450,8 @@ void rvo_destroy(rvo_ctx* c) {
     if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
     if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
   }
-  for (int i = 0; i < 2; i++) {
-    hipEvent_t* evs[6] = {&c->ev_f[i], &c->ev_p[i], &c->ev_t[i], &c->ev_up[i], &c->ev_pyr2[i], &c->ev_rot2[i]};
+  for (int i = 0; i < rvo_ctx::kPairSets; i++) {
+    hipEvent_t* evs[5] = {&c->ev_f[i], &c->ev_p[i], &c->ev_t[i], &c->ev_pyr2[i], &c->ev_rot2[i]};
     for (auto e : evs) if (*e) (void)hipEventDestroy(*e);
   }
   for (int i = 0; i < rvo_ctx::kSlotRing; i++) if (c->ev_pdone[i]) (void)hipEventDestroy(c->ev_pdone[i]);
@@ -462,7 +468,7 @@ void rvo_destroy(rvo_ctx* c) {
 // Orders the context's main stream after every staged batch still in flight (their pair and tail stages run on other
 // streams): called by every entry point that touches pair work areas or frame slots outside the staged pipeline.
 static int join_staged(rvo_ctx* c) {
-  for (int s = 0; s < 2; s++) {
+  for (int s = 0; s < rvo_ctx::kPairSets; s++) {
     if (!(c->staged_pending & (1 << s))) continue;
     if (c->ev_p_rec[s]) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_p[s], 0));
     if (c->ev_t_rec[s]) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_t[s], 0));

@@ -229,7 +229,7 @@ def test_batches_in_flight_on_two_contexts_are_independent_and_deterministic(sce
         c.close()
 
 
-@pytest.mark.parametrize("slot_sets", [3, 1])
+@pytest.mark.parametrize("slot_sets", [5, 2, 1])
 def test_staged_pipeline_in_one_context_equals_a_context_working_alone(scene, intr640, slot_sets, monkeypatch):
     """rvo_set_pipeline(1): one context keeps the frame stages of batch k+1, the pair stages of batch k and the tail of
     batch k-1 on its four streams.  Every batch must give the bits of a context that runs it alone as one chain; with a

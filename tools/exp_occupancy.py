@@ -8,8 +8,9 @@ sys.path.insert(0, root)
 nctx = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 extra = sys.argv[3].split() if len(sys.argv) > 3 else []
-so = "/tmp/librgbdvo_occ.so"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+so = os.environ.get("RVO_OCC_LIB", "/tmp/librgbdvo_occ.so")  # a library built beforehand with -DRVO_OCC, or build one now
+if "RVO_OCC_LIB" not in os.environ:
+  subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                        "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-DRVO_OCC", "-Wno-unused-result", *extra,
                        "-o", so, os.path.join(root, "slam_amd/csrc/rvo.hip")])
 os.environ["RVO_LIB"] = so
@@ -48,8 +49,9 @@ res = np.cumsum(seg, axis=1)
 print(f"{nctx} contexts, {steps} batches in {dt * 1e3:.2f} ms = {dt / steps * 1e3:.4f} ms/batch; timeline {hi - lo + 1} buckets of 10 us")
 hdr = "  t(us) " + " ".join(f"{names[k]:>7s}" for k in sorted(names))
 print(hdr)
-for b in range(0, seg.shape[1]):
-    if b > 400: break
+b0 = int(os.environ.get("OCC_START", "0"))
+for b in range(b0, seg.shape[1]):
+    if b > b0 + 400: break
     print(f"{b * 10:7d} " + " ".join(f"{res[k, b]:7d}" for k in sorted(names)))
 print("resident-WG x time (WG*ms per batch):", {names[k]: round(res[k].sum() * 0.01 / steps, 2) for k in sorted(names)})
 busy = {names[k]: float((res[k] > 0).mean()) for k in sorted(names)}

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
+#include <string>
 #include <vector>
 __global__ void spin(long long ticks, int* sink) {
   const long long t0 = wall_clock64();
@@ -15,10 +17,13 @@ int main(int argc, char** argv) {
   int lo = 0, hi = 0;
   hipDeviceGetStreamPriorityRange(&lo, &hi);
   printf("priority range: least %d greatest %d\n", lo, hi);
-  const bool prio = argc > 2;
+  // argv[2]: one letter per stream (h = greatest priority, l = least, anything else = normal); "half" = second half high
+  const char* pr = argc > 2 ? argv[2] : "";
+  const bool half = std::string(pr) == "half";
+  hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, 0, 1000, nullptr);  // the null stream takes its queue first, as under torch
   for (int i = 0; i < n; i++) {
-    if (prio) hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, i < n / 2 ? 0 : hi);  // second half: high priority
-    else hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
+    const char ch = half ? (i < n / 2 ? 'n' : 'h') : (i < (int)strlen(pr) ? pr[i] : 'n');
+    hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, ch == 'h' ? hi : ch == 'l' ? lo : 0);
   }
   const long long ticks = 200000;  // 2 ms at 100 MHz
   for (auto& s : st) { hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, s, 1000, nullptr); }
