@@ -679,30 +679,38 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   }
   // ---- descriptors of the kept keypoints (ExtractAlignedDescriptor + Normalized twice, feature.cpp:6140-6156,
   // 6193-6207) straight from the LDS tile: the 9x9 window of a keypoint of this cell lies inside the cell + 4 px halo.
-  // 16 lanes per keypoint; lane l owns descriptor dword l (taps 4l..4l+3), lanes 0-3 also dwords 16-19.
+  // 8 lanes per keypoint, so the default 25 kept keypoints are one pass of the 32 groups: lane l owns descriptor dwords
+  // l and 8 + l (taps 4l.., 32 + 4l..) and the two bytes 64 + 2l, 65 + 2l -- ten taps per lane.
   {
-    const int sub = tid & 15, grp = tid >> 4;
-    const bool two = sub < (RVO_DESC_LEN - 64) / 4;
-    for (int i = grp; i < keep; i += 16) {
+    static_assert(RVO_DESC_LEN == 80, "lane -> tap assignment below");
+    const int sub = tid & 7, grp = tid >> 3;
+    int toff[10];
+#pragma unroll
+    for (int m = 0; m < 10; m++) {
+      const int t = m < 4 ? 4 * sub + m : m < 8 ? 32 + 4 * sub + (m - 4) : 64 + 2 * sub + (m - 8);
+      toff[m] = (t / 9 - 4) * TP + (t % 9 - 4);
+    }
+    for (int i = grp; i < keep; i += 32) {
       const uint32_t k = s_list[i];
       const uint8_t* c = s_tile + (kp_y(k) - cy0 + 4) * TP + (kp_x(k) - cx0 + 4 + shl);
-      int v[8];
+      int v[10];
 #pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const int t = (m < 4 ? 4 * sub : 64 + 4 * sub) + (m & 3);
-        v[m] = (m < 4 || two) ? (int)c[(t / 9 - 4) * TP + (t % 9 - 4)] : 0;
-      }
+      for (int m = 0; m < 10; m++) v[m] = (int)c[toff[m]];
 #pragma unroll
       for (int pass = 0; pass < 2; pass++) {
-        const int mean = sum16(v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]) / RVO_DESC_LEN;
+        int sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) + (v[8] + v[9]);
+        sum += __builtin_amdgcn_update_dpp(0, sum, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        sum += __builtin_amdgcn_update_dpp(0, sum, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        sum += __builtin_amdgcn_update_dpp(0, sum, 0x141, 0xF, 0xF, true);  // row_half_mirror: the 8 lanes of the group
+        const int mean = sum / RVO_DESC_LEN;
         const int o = 128 - mean;  // mean < 128: add and clamp at 255; mean > 128: subtract and clamp at 0
 #pragma unroll
-        for (int m = 0; m < 8; m++) v[m] = min(255, max(0, v[m] + o));
-        if (!two) { v[4] = v[5] = v[6] = v[7] = 0; }
+        for (int m = 0; m < 10; m++) v[m] = min(255, max(0, v[m] + o));
       }
-      uint32_t* dsc = reinterpret_cast<uint32_t*>(fb.bk_desc + (bslot + i) * RVO_DESC_LEN);
-      dsc[sub] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
-      if (two) dsc[16 + sub] = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
+      uint8_t* dsc = fb.bk_desc + (bslot + i) * RVO_DESC_LEN;
+      reinterpret_cast<uint32_t*>(dsc)[sub] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+      reinterpret_cast<uint32_t*>(dsc)[8 + sub] = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
+      reinterpret_cast<uint16_t*>(dsc)[32 + sub] = (uint16_t)(v[8] | (v[9] << 8));
     }
   }
   FAST_PHASE(6);  // lists + descriptors (thread 0's share)

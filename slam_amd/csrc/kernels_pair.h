@@ -565,10 +565,12 @@ __device__ inline int group16_sum(int v) {
 // int32, so the lane split does not change any value.  Branches below are uniform within a 16-lane group.
 __global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
   RVO_OCC_SCOPE(7, 16);
-  const int pair = blockIdx.y + pb.pair0;
+  int bx, py;  // XCD-aware: the workgroups of a pair run on one XCD, whose L2 then holds the pair's two images once
+  xcd_map(gridDim.x, gridDim.y, blockIdx.x, blockIdx.y, &bx, &py);
+  const int pair = py + pb.pair0;
   if (!pb.active[pair]) return;
   const int gl = threadIdx.x & (REFINE_GROUP - 1);
-  const int i_grp = blockIdx.x * (256 / REFINE_GROUP) + (threadIdx.x / REFINE_GROUP);
+  const int i_grp = bx * (256 / REFINE_GROUP) + (threadIdx.x / REFINE_GROUP);
   int off[RVO_MAX_LEVELS + 1];
   off[0] = 0;
   for (int l = 0; l < g.levels; l++) off[l + 1] = off[l] + pb.lm_cnt[pair * RVO_MAX_LEVELS + l];
