@@ -106,6 +106,13 @@ def depth_to_cloud(depth: np.ndarray, x_to_z: float, y_to_z: float) -> np.ndarra
     return out
 
 
+def set_perturbation(norm_order: int = 0, true_division: int = 0, q_noise_rad: float = 0.0, seed: int = 1, rot_float: int = 0):
+    """Process-wide perturbation of the oracle's conventions (struct Perturb, rvo_oracle.cpp); all zero = the oracle."""
+    L = lib()
+    L.orc_set_perturbation.argtypes = [C.c_int, C.c_int, C.c_double, C.c_uint, C.c_int]
+    L.orc_set_perturbation(norm_order, true_division, q_noise_rad, seed, rot_float)
+
+
 class Oracle:
     def __init__(self, intr: dict, params: Params | None = None):
         self.L = lib()
@@ -184,6 +191,15 @@ class Oracle:
         r = PairResult()
         self.L.orc_match_pair(self.h, C.c_int(ref_slot), C.c_int(tgt_slot), C.byref(r))
         return result_to_dict(r)
+
+    MARGIN_NAMES = ("window", "refine_gate", "esm_step", "sse_tie", "clique", "reproj_gate", "mean_reproj", "gn_sse_rel",
+                    "degree_gap", "n_window", "n_clique", "n_esm")
+
+    def margins(self) -> dict:
+        """Distances of the last EstimateMotion's decided quantities to their thresholds (struct Margins, rvo_oracle.cpp)."""
+        out = np.zeros(12)
+        self.L.orc_get_margins(self.h, _p(out))
+        return dict(zip(self.MARGIN_NAMES, out.tolist()))
 
     def matches(self, n):
         ints = np.zeros((n, 7), np.int32)

@@ -75,6 +75,36 @@ enum { MATCH_NEEDS_DEPTH_REFINEMENT = 0, MATCH_REFINEMENT_FAILED, MATCH_OK };  /
 
 inline int round_up(int x, int a) { int r = x % a; return r ? x + (a - r) : x; }  // helper.hpp:36-42
 
+// ---------------------------------------------------------------- stability margins
+// How far the quantities the path DECIDES on sit from their thresholds, and what happens to the decided sets when the
+// parts of this restatement that are conventions (Eigen's evaluation order, the initial-rotation solver) are perturbed.
+// Recorded per EstimateMotion call; read with orc_get_margins.  Test instrumentation only: it changes no result.
+struct Margins {
+  double window = INFINITY;       // | ||proj - kp|| - feature_search_window |            motion_estimate.cpp:335     [px]
+  double refine_gate = INFINITY;  // | ||kp - refined|| - 1.5 |  (moved matches only)      motion_estimate.cpp:360-366 [px]
+  double esm_step = INFINITY;     // | max(|dx|,|dy|) - 0.1 | over ESM iterations          motion_estimate.cpp:894     [px]
+  double sse_tie = INFINITY;      // | sse - final_sse | over ESM iterations (integers)    motion_estimate.cpp:882
+  double clique = INFINITY;       // | |dref - dtgt| - clique_inlier_threshold |           motion_estimate.cpp:507     [m]
+  double reproj_gate = INFINITY;  // | e - inlier_max_reprojection_error | over inliers    motion_estimate.cpp:204-214 [px]
+  double mean_reproj = INFINITY;  // | mean e - max_mean_reprojection_error |              motion_estimate.cpp:229     [px]
+  double gn_sse_rel = INFINITY;   // | sse - final_sse | / final_sse over GN iterations    motion_estimate.cpp:1296
+  double degree_gap = INFINITY;   // smallest gap between the degrees of two matches that are adjacent after the sort and
+                                  // on different sides of the inlier decision (0: a tie decided by std::sort's order)
+  double n_window = 0, n_clique = 0, n_esm = 0;  // number of decisions behind window / clique / esm_step
+  void note(double* slot, double v) { if (v < *slot) *slot = v; }
+};
+// Perturbations of the conventions (orc_set_perturbation; process-wide, tests only)
+struct Perturb {
+  int norm_order = 0;    // bit 0: Vector3d::norm() as sqrt((x*x + y*y) + z*z) instead of sqrt(x*x + (y*y + z*z));
+                         // bit 1: 4-term dot products (P * point) pairwise instead of left to right
+  int true_division = 0; // 1: `uvw /= w` as true divisions instead of a multiplication by 1/w
+  int rot_float = 0;     // 1: EstimateInitialRotation's 3x3 normal equations accumulated and solved in fp32 (a solver with
+                         //    cond^2 * eps_float error: an upper bound for what the reference's float JacobiSVD can differ by)
+  double q_noise = 0;    // rotate the initial-rotation quaternion by this angle [rad] about a pseudo-random axis
+  unsigned seed = 1;
+};
+static Perturb g_pert;
+
 // ---------------------------------------------------------------- isometry
 struct Iso {
   double R[3][3];
@@ -801,6 +831,7 @@ void reverse_jac_mats(const double prm[6], double fx, double px, double py, JacM
 }
 
 inline double dot4(const double* r, const double* p) {
+  if (g_pert.norm_order & 2) return (r[0] * p[0] + r[1] * p[1]) + (r[2] * p[2] + r[3] * p[3]);  // pairwise (vectorised Eigen)
   return ((r[0] * p[0] + r[1] * p[1]) + r[2] * p[2]) + r[3] * p[3];
 }
 
@@ -854,6 +885,7 @@ struct MotionEstimator {
   int status = NO_DATA;
   Frame* ref = nullptr;
   Frame* tgt = nullptr;
+  Margins mg;
 
   MotionEstimator(const Camera* c, const Params* p) : cam(c), prm(p) {
     motion.setIdentity();
@@ -904,7 +936,10 @@ struct MotionEstimator {
       tl.dx.ExtractInterp(tg, ntx, nty, tgt_desc.data());
       for (int i = 0; i < len; i++) err[i] = tgt_desc[i] - ref_desc[i];
       int sse = dot_i16(err.data(), err.data(), nel);
+      mg.note(&mg.sse_tie, fabs((double)sse - (double)final_sse));
       if (sse < final_sse) { tx = ntx; ty = nty; final_sse = sse; } else break;
+      mg.note(&mg.esm_step, fabs(std::max(fabs(dxs), fabs(dys)) - 0.1));
+      mg.n_esm++;
       if (fabs(dxs) < 0.1 && fabs(dys) < 0.1) break;
     }
     final_uv[0] = tx; final_uv[1] = ty;
@@ -925,11 +960,15 @@ struct MotionEstimator {
       double uvw[3] = {dot4(RP[0], x), dot4(RP[1], x), dot4(RP[2], x)};
       double inv = 1.0 / uvw[2];  // Eigen 3.2: v /= s  ==  v *= 1/s
       double pu = uvw[0] * inv, pv = uvw[1] * inv;
+      if (g_pert.true_division) { pu = uvw[0] / uvw[2]; pv = uvw[1] / uvw[2]; }
       for (int t = 0; t < nt; t++) {
         double tu = (float)tl.kps[t].rect_base_uv[0];  // const float getters, pyramid.hpp:95-101
         double tv = (float)tl.kps[t].rect_base_uv[1];
         double ex = tu - pu, ey = tv - pv;
-        if (sqrt(ex * ex + ey * ey) < prm->feature_search_window) cand[r].push_back(t);
+        double dist = sqrt(ex * ex + ey * ey);
+        mg.note(&mg.window, fabs(dist - prm->feature_search_window));
+        mg.n_window++;
+        if (dist < prm->feature_search_window) cand[r].push_back(t);
       }
     }
     // FeatureMatcher::matchFeatures
@@ -964,6 +1003,7 @@ struct MotionEstimator {
       refineFeatureMatch(rl, tl, ruv, iuv, fuv);
       double dx = iuv[0] - fuv[0], dy = iuv[1] - fuv[1];
       double ds = sqrt(dx * dx + dy * dy);
+      if (ds > 0) mg.note(&mg.refine_gate, fabs(ds - 1.5));
       if (ds < 1e-9 || ds > 1.5) {
         m.refined_target_keypoint = *m.target_keypoint;
         m.status = MATCH_OK;
@@ -998,10 +1038,12 @@ struct MotionEstimator {
           consistent = true;
         } else {
           double dx = r2[0] - r1[0], dy = r2[1] - r1[1], dz = r2[2] - r1[2];
-          double ref_dist = sqrt(dx * dx + (dy * dy + dz * dz));
+          double ref_dist = (g_pert.norm_order & 1) ? sqrt((dx * dx + dy * dy) + dz * dz) : sqrt(dx * dx + (dy * dy + dz * dz));
           dx = t2[0] - t1[0]; dy = t2[1] - t1[1]; dz = t2[2] - t1[2];
-          double tgt_dist = sqrt(dx * dx + (dy * dy + dz * dz));
+          double tgt_dist = (g_pert.norm_order & 1) ? sqrt((dx * dx + dy * dy) + dz * dz) : sqrt(dx * dx + (dy * dy + dz * dz));
           consistent = fabs(ref_dist - tgt_dist) < thr;
+          mg.note(&mg.clique, fabs(fabs(ref_dist - tgt_dist) - thr));  // NaN distances (no depth) never lower the minimum
+          mg.n_clique++;
         }
         if (consistent) {
           a.consistency_vec[b.id] = 1; a.compatibility_degree++;
@@ -1025,6 +1067,11 @@ struct MotionEstimator {
       num_inliers++;
       for (int r = m + 1; r < N; r++) { int o = matches[r].id; if (!reject[o] && !c.consistency_vec[o]) reject[o] = 1; }
     }
+    // std::sort is not stable: where two neighbours of the sorted order have equal degrees and different verdicts, the
+    // verdict may hang on the order libstdc++ leaves them in (which the HIP path replays); report the smallest such gap
+    for (int m = 1; m < N; m++)
+      if (matches[m].inlier != matches[m - 1].inlier)
+        mg.note(&mg.degree_gap, (double)(matches[m - 1].compatibility_degree - matches[m].compatibility_degree));
   }
 
   // motion_estimate.cpp:610-682 -> 1208-1331
@@ -1081,6 +1128,7 @@ struct MotionEstimator {
       reproj_error(txyz, rproj, fx, px, py, nest, &err[0]);
       reproj_error(rxyz, tproj, fx, px, py, iso_inverse(nest), &err[2 * n]);
       double sse = sse_of(err);
+      if (final_sse > 0) mg.note(&mg.gn_sse_rel, fabs(sse - final_sse) / final_sse);
       if (sse > final_sse) break;  // NaN sse falls through, as in the reference
       memcpy(est, next, sizeof(est));
       final_sse = sse;
@@ -1125,6 +1173,7 @@ struct MotionEstimator {
     for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) cov[i][j] = 0;
     mean_reprojection_error = 0;
     matches.clear();
+    mg = Margins();
     for (int l = 0; l < ref->num_levels; l++) matchFeatures(l);
     // Depth::RefineXYZ, depth.cpp:80-95 (depth source = the target frame's depth image)
     for (auto& m : matches)
@@ -1140,12 +1189,14 @@ struct MotionEstimator {
     num_reprojection_failures = 0;
     for (auto& m : matches) {
       if (!m.inlier) continue;
+      if (status == SUCCESS) mg.note(&mg.reproj_gate, fabs(m.reprojection_error - prm->inlier_max_reprojection_error));
       if (m.reprojection_error > prm->inlier_max_reprojection_error) {
         m.inlier = false; num_inliers--; num_reprojection_failures++;
       }
     }
     refineMotionEstimate();
     computeReprojectionError();
+    if (status == SUCCESS) mg.note(&mg.mean_reproj, fabs(mean_reprojection_error - prm->max_mean_reprojection_error));
     if (mean_reprojection_error > prm->max_mean_reprojection_error) status = REPROJECTION_ERROR;
   }
 
@@ -1242,6 +1293,8 @@ struct MotionEstimator {
           float j2 = jx * (float)(y + 1) - jy * (float)(x + 1);
           double J[3] = {jx, jy, j2};
           for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) A[a][c] += J[a] * J[c]; b[a] += J[a] * e[i]; }
+          if (g_pert.rot_float)  // every partial sum rounded to fp32
+            for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) A[a][c] = (float)A[a][c]; b[a] = (float)b[a]; }
         }
       double lie[3] = {0, 0, 0};
       double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
@@ -1258,6 +1311,7 @@ struct MotionEstimator {
         inv[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det;
         inv[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
         inv[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+        if (g_pert.rot_float) for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) inv[a][c] = (float)inv[a][c];
         for (int a = 0; a < 3; a++) lie[a] = (float)(-2 * ((inv[a][0] * b[0] + inv[a][1] * b[1]) + inv[a][2] * b[2]));
       }
       // lieToH 1528-1536: exp of [[0,l2,l0],[-l2,0,l1],[0,0,0]]
@@ -1280,7 +1334,19 @@ struct MotionEstimator {
     double h12 = (double)(float)(bestH[1][2] * (float)sf), h02 = (double)(float)(bestH[0][2] * (float)sf);
     double fx = cam->in.fx;
     double roll = asin(h12 / fx), pitch = -asin(h02 / fx), yaw = -atan2((double)bestH[1][0], (double)bestH[0][0]);
-    return rpy_to_quat(roll, pitch, yaw);
+    Quat q = rpy_to_quat(roll, pitch, yaw);
+    if (g_pert.q_noise != 0) {  // stand-in for what a different solver (the reference's float JacobiSVD) may leave: H3
+      unsigned st = g_pert.seed * 2654435761u + 12345u;
+      double ax[3];
+      for (int k = 0; k < 3; k++) { st = st * 1664525u + 1013904223u; ax[k] = (double)(st >> 8) / (1 << 24) - 0.5; }
+      double nn = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+      double h = 0.5 * g_pert.q_noise, sh = sin(h) / nn;
+      Quat d{cos(h), ax[0] * sh, ax[1] * sh, ax[2] * sh};
+      Quat r{q.w * d.w - q.x * d.x - q.y * d.y - q.z * d.z, q.w * d.x + q.x * d.w + q.y * d.z - q.z * d.y,
+             q.w * d.y - q.x * d.z + q.y * d.w + q.z * d.x, q.w * d.z + q.x * d.y - q.y * d.x + q.z * d.w};
+      q = r;
+    }
+    return q;
   }
 };
 
@@ -1519,6 +1585,18 @@ void orc_match_pair(void* cv, int ref_slot, int tgt_slot, PairResult* out) {
   iso_rotate(&init, q);
   c->est.EstimateMotion(c->slot(ref_slot), c->slot(tgt_slot), init);
   fill_result(c->est, out);
+}
+
+// margins of the last EstimateMotion (struct Margins, 12 doubles in declaration order)
+void orc_get_margins(void* cv, double* out12) {
+  const Margins& m = ((Ctx*)cv)->est.mg;
+  const double v[12] = {m.window, m.refine_gate, m.esm_step, m.sse_tie, m.clique, m.reproj_gate, m.mean_reproj, m.gn_sse_rel,
+                        m.degree_gap, m.n_window, m.n_clique, m.n_esm};
+  memcpy(out12, v, sizeof(v));
+}
+void orc_set_perturbation(int norm_order, int true_division, double q_noise_rad, unsigned seed, int rot_float) {
+  g_pert.norm_order = norm_order; g_pert.true_division = true_division; g_pert.q_noise = q_noise_rad; g_pert.seed = seed;
+  g_pert.rot_float = rot_float;
 }
 
 // dump of the last EstimateMotion's match array (post-sort order)
