@@ -50,6 +50,25 @@ def make_batch(n_pairs: int, seed0: int):
     return gray, depth, np.stack([o[4] for o in out])
 
 
+def _render_seq_frame(args):
+    T, = args
+    from slam_amd import synth
+    intr = synth.default_intrinsics(640, 480)
+    return synth.PlaneScene().render(intr, T, 0.0, None)
+
+
+def make_sequence_frames(n_frames: int, seed: int = 0):
+    """configs[0]: one 640x480 stream over a textured plane (slam_amd.synth.make_sequence's trajectory), rendered by a pool."""
+    from concurrent.futures import ProcessPoolExecutor
+    from slam_amd import synth
+    synth.make_texture()
+    poses, _ = synth.sequence_poses(n_frames, seed)
+    workers = int(os.environ.get("RVO_BENCH_WORKERS", "8"))
+    with ProcessPoolExecutor(max_workers=workers) as ex:
+        out = list(ex.map(_render_seq_frame, [(T,) for T in poses], chunksize=4))
+    return np.stack([o[0] for o in out]), np.stack([o[1] for o in out]), poses
+
+
 def algorithmic_bytes(geom: dict, stats: dict) -> dict:
     """Algorithmic HBM bytes per LAUNCH of each kernel kind (definitions: DESIGN.md section 5)."""
     W, H, L = geom["W"], geom["H"], geom["levels"]
@@ -80,6 +99,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="passes over those pairs (about 10 s of CPU work in all)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--seq-frames", type=int, default=300, help="frames of the configs[0] sequence timed on the CPU oracle (0 = skip)")
     ap.add_argument("--prewarm", type=float, default=float(os.environ.get("RVO_BENCH_PREWARM_S", "1.0")),
                     help="seconds of untimed work before the warm-up steps (clocks of an idle box)")
     a = ap.parse_args()
@@ -106,6 +126,9 @@ def main():
 
     # synthetic inputs first (forks workers; nothing has touched the GPU yet)
     gray, depth, T_gt = make_batch(n_pairs, seed0=100000 * rank)
+    seq = None
+    if world == 1 and not a.no_cpu and a.seq_frames > 0:
+        seq = make_sequence_frames(a.seq_frames)
 
     log("inputs made")
     import torch
@@ -338,17 +361,53 @@ def main():
             cpu = dict(value=m * a.cpu_reps / cdt, unit="frame-pairs/s", cores=1, kind="port",
                        sample=f"first {m} of the same {n_pairs} pairs x {a.cpu_reps} passes ({cdt:.1f} s), oracle/librvo_oracle.so single thread; "
                               f"{same}/{m} pairs have identical match/inlier counts and status to the GPU result")
+        cpu_seq = None
+        if seq is not None:
+            # configs[0]: the reference's own CPU-runnable case -- RGBDVO::ProcessFrame over one 300-frame stream (100
+            # warm-up frames that only adapt the FAST threshold, vo.cpp:58-69, then one EstimateMotion per frame), on the
+            # oracle with one core, and the same stream through the library (rvo_stream_step, one stream, host images in)
+            from oracle.pyoracle import Oracle, OracleVO, default_params as odef
+            from slam_amd.api import RGBDVOStreams
+            log("cpu sequence leg")
+            sg, sd, sposes = seq
+            so = Oracle(intr, odef())
+            vo = OracleVO(so)
+            s0 = time.perf_counter()
+            ro_seq = [vo.process(sg[i], sd[i]) for i in range(len(sg))]
+            sdt = time.perf_counter() - s0
+            vo.close()
+            so.close()
+            gs = RGBDVOStreams(intr, 1, device=dev_index)
+            g0 = time.perf_counter()
+            rg_seq = [gs.ProcessFrame(sg[i:i + 1], sd[i:i + 1])[0] for i in range(len(sg))]
+            gdt = time.perf_counter() - g0
+            gs.ctx.close()
+            same_seq = sum(int(a_["status"] == b_["status"] and a_["num_inliers"] == b_["num_inliers"] and
+                               a_["num_matches"] == b_["num_matches"] and a_["keyframe_changed"] == b_["keyframe_changed"])
+                           for a_, b_ in zip(ro_seq, rg_seq))
+            dpose = max(float(np.abs(a_["pose"] - b_["pose"]).max()) for a_, b_ in zip(ro_seq, rg_seq))
+            k0 = next(i for i, r_ in enumerate(ro_seq) if r_["rc"] == 1)  # first frame after the warm-up: pose = Identity there
+            terr = float(np.abs(ro_seq[-1]["pose"][:, 3] - (np.linalg.inv(sposes[k0]) @ sposes[-1])[:3, 3]).max())
+            cpu_seq = dict(value=len(sg) / sdt, unit="frames/s", cores=1, kind="port",
+                           sample=f"configs[0]: one {len(sg)}-frame synthetic 640x480 stream through OracleVO (vo.cpp:55-165), "
+                                  f"{sdt:.1f} s, single thread",
+                           estimates_success=sum(r_["status"] == 1 for r_ in ro_seq),
+                           gpu_same_stream_frames_per_s=len(sg) / gdt,
+                           gpu_note="the same stream alone through rvo_stream_step (host images in, one frame per call): "
+                                    "latency-bound, the GPU is built for many streams (configs[2])",
+                           frames_identical_to_gpu=same_seq, max_abs_pose_diff_vs_gpu=dpose,
+                           drift_after_all_frames_m=terr)
         line = dict(metric="frame-pairs/sec (whole node) at 640x480", value=value, unit="frame-pairs/s",
                     n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8/int32/f64", data="synthetic",
                     config=dict(workload=f"configs[1]: {n_pairs} independent synthetic 640x480 gray+depth frame pairs "
                                          f"per GPU, 3-level pyramid, default feature grid (80x80x25), device-resident inputs",
-                                pairs_per_gpu=n_pairs, contexts=n_ctx, pipeline="staged (4 streams, 2 work-area sets)" if n_ctx == 1 else f"{n_ctx} contexts, alternate batches",
+                                pairs_per_gpu=n_pairs, contexts=n_ctx, pipeline="staged (4 streams, 4 work-area sets, 5 frame-slot sets)" if n_ctx == 1 else f"{n_ctx} contexts, alternate batches",
                                 parallelism=f"dp{world} (independent pairs, no collective in loop)"),
                     roofline=roof,
                     roofline_path=dict(bytes_per_pair=b_pair, frac=value / world * b_pair / HBM_PEAK,
                                        note="SURVEY 8(d) B_pair at the measured K and N, per GPU"),
-                    roofline_valu=roof_valu, cpu_baseline=cpu, cpu_baseline_all_cores=cpu_multi, kernels=kernels,
+                    roofline_valu=roof_valu, cpu_baseline=cpu, cpu_baseline_all_cores=cpu_multi, cpu_baseline_sequence=cpu_seq, kernels=kernels,
                     kernels_steps=post_steps,
                     kernels_note=f"separate pass of {post_steps} steps after the timed region with HIP events around every launch "
                                  "(that instrumentation costs about 7 %); the timed region brackets only the dominant kernel", stats=stats,

@@ -221,30 +221,30 @@ void rvo_default_fm_params(rvo_params* p) {
   p->reference_frame_change_threshold = 150;
 }
 
-// Camera::MakeXYMap, camera.cpp:16-67 (host, once per context)
-static void make_xy_map(const rvo_intrinsics& in, std::vector<float>& X, std::vector<float>& Y) {
-  const int W = in.width, H = in.height;
-  X.resize((size_t)W * H);
-  Y.resize((size_t)W * H);
-  const double fx = in.fx, fy = in.fy, cx = in.cx, cy = in.cy, fxp = in.fx, fyp = in.fy, cxp = in.cx, cyp = in.cy;
-  const double k1 = in.k1, k2 = in.k2, k3 = in.k3, p1 = in.p1, p2 = in.p2;
-  for (int y = 0; y < H; ++y)
-    for (int x = 0; x < W; ++x) {
-      double x1 = (x - cx) / fx, y1 = (y - cy) / fy;
-      const double x0 = x1, y0 = y1;
-      for (int j = 0; j < 5; ++j) {
-        const double r2 = x1 * x1 + y1 * y1;
-        const double icdist = 1. / (1. + ((k3 * r2 + k2) * r2 + k1) * r2);
-        const double deltaX = 2 * p1 * x1 * y1 + p2 * (r2 + 2 * x1 * x1);
-        const double deltaY = p1 * (r2 + 2 * y1 * y1) + 2 * p2 * x1 * y1;
-        x1 = (x0 - deltaX) * icdist;
-        y1 = (y0 - deltaY) * icdist;
-      }
-      x1 = x1 * fxp + cxp;
-      y1 = y1 * fyp + cyp;
-      X[(size_t)y * W + x] = (float)x1;
-      Y[(size_t)y * W + x] = (float)y1;
-    }
+// Undistortion look-up tables (what Camera::MakeXYMap, camera.cpp:16-67, leaves in Xmap_ / Ymap_): for every input pixel
+// the position it has in the rectified image.  One thread per pixel, once per context.  The lens model is inverted by
+// five rounds of fixed-point iteration from the normalised pixel; every round evaluates the radial polynomial in Horner
+// form and the two tangential terms on the current estimate.  fp64 throughout, no contraction, the reference's operation
+// order (the tables must come out bit-equal: tests/test_gpu_frame.py), then one rounding to float.
+struct LensModel { double fx, fy, cx, cy, k1, k2, k3, p1, p2; };
+__global__ __launch_bounds__(256) void k_undistort_lut(LensModel lens, int width, int height, float* __restrict__ lut_u,
+                                                       float* __restrict__ lut_v) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+  if (col >= width || row >= height) return;
+  const double nu = (col - lens.cx) / lens.fx, nv = (row - lens.cy) / lens.fy;  // distorted, normalised
+  double u = nu, v = nv;                                                        // running undistorted estimate
+  for (int round = 0; round < 5; round++) {
+    const double rr = u * u + v * v;
+    const double radial_inv = 1. / (1. + ((lens.k3 * rr + lens.k2) * rr + lens.k1) * rr);
+    const double tang_u = 2 * lens.p1 * u * v + lens.p2 * (rr + 2 * u * u);
+    const double tang_v = lens.p1 * (rr + 2 * v * v) + 2 * lens.p2 * u * v;
+    u = (nu - tang_u) * radial_inv;
+    v = (nv - tang_v) * radial_inv;
+  }
+  // the rectified camera has the input camera's focal lengths and centre (camera.cpp:7-12)
+  const size_t at = (size_t)row * width + col;
+  lut_u[at] = (float)(u * lens.fx + lens.cx);
+  lut_v[at] = (float)(v * lens.fy + lens.cy);
 }
 
 // Everything rvo_create does once the context object exists; on any failure the caller destroys the half-built context
@@ -421,11 +421,18 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
   HIPCHK(hipMemset(fb.kp_cnt, 0, F * RVO_MAX_LEVELS * 4));
   HIPCHK(hipMemset(fb.det_cnt, 0, F * RVO_MAX_LEVELS * 4));
   HIPCHK(hipMemset(fb.grid_cnt, 0, F * RVO_MAX_LEVELS * 4));
-  make_xy_map(*intr, c->xmap, c->ymap);
-  HIPCHK(hipMemset(dx, 0, ((size_t)g.W * g.H + g.W + 2) * 4));
-  HIPCHK(hipMemset(dy, 0, ((size_t)g.W * g.H + g.W + 2) * 4));
-  HIPCHK(hipMemcpy(dx, c->xmap.data(), c->xmap.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dy, c->ymap.data(), c->ymap.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemsetAsync(dx, 0, ((size_t)g.W * g.H + g.W + 2) * 4, c->stream));  // same stream as the kernel below
+  HIPCHK(hipMemsetAsync(dy, 0, ((size_t)g.W * g.H + g.W + 2) * 4, c->stream));
+  {
+    const LensModel lens{intr->fx, intr->fy, intr->cx, intr->cy, intr->k1, intr->k2, intr->k3, intr->p1, intr->p2};
+    hipLaunchKernelGGL(k_undistort_lut, dim3((g.W + 255) / 256, g.H), dim3(256), 0, c->stream, lens, g.W, g.H, dx, dy);
+    HIPCHK(hipGetLastError());
+    c->xmap.resize((size_t)g.W * g.H);  // host copies for rvo_get_lut
+    c->ymap.resize((size_t)g.W * g.H);
+    HIPCHK(hipMemcpyAsync(c->xmap.data(), dx, c->xmap.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->ymap.data(), dy, c->ymap.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
   fb.xmap = dx; fb.ymap = dy;
 
   rc = pair_alloc(c);

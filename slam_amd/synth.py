@@ -163,6 +163,23 @@ def make_pair(seed: int, intr: dict | None = None, scene: PlaneScene | None = No
     return g0, d0, g1, d1, np.linalg.inv(T_w_ref) @ T_w_tgt
 
 
+def sequence_poses(n_frames: int, seed: int = 0) -> tuple:
+    """Camera poses T_w_c of make_sequence's trajectory (a pure function of the frame index, so frames can be rendered
+    independently, e.g. by a process pool).  Returns (poses, the generator make_sequence goes on to render with)."""
+    rng = np.random.default_rng(5000 + seed)
+    ph = rng.uniform(0, 2 * np.pi, 6)
+    start = rng.uniform(-0.5, 0.5, 3) * np.array([1, 1, 0.2])
+    out = []
+    for i in range(n_frames):
+        s = i / 30.0
+        t = start + np.array([0.35 * np.sin(0.9 * s + ph[0]), 0.25 * np.sin(0.7 * s + ph[1]),
+                              0.10 * np.sin(0.5 * s + ph[2])])
+        r = np.deg2rad(np.array([3.0 * np.sin(0.8 * s + ph[3]), 3.0 * np.sin(0.6 * s + ph[4]),
+                                 4.0 * np.sin(0.5 * s + ph[5])]))
+        out.append(make_pose(t, r))
+    return out, rng
+
+
 def make_sequence(n_frames: int, seed: int = 0, intr: dict | None = None, scene: PlaneScene | None = None,
                   invalid_frac: float = 0.0):
     """Smooth trajectory (BASELINE config 1 / one stream of config 3): <= 2 cm and <= 0.5 deg per frame.
@@ -171,15 +188,7 @@ def make_sequence(n_frames: int, seed: int = 0, intr: dict | None = None, scene:
     """
     intr = intr or default_intrinsics()
     scene = scene or PlaneScene()
-    rng = np.random.default_rng(5000 + seed)
-    ph = rng.uniform(0, 2 * np.pi, 6)
-    start = rng.uniform(-0.5, 0.5, 3) * np.array([1, 1, 0.2])
-    for i in range(n_frames):
-        s = i / 30.0
-        t = start + np.array([0.35 * np.sin(0.9 * s + ph[0]), 0.25 * np.sin(0.7 * s + ph[1]),
-                              0.10 * np.sin(0.5 * s + ph[2])])
-        r = np.deg2rad(np.array([3.0 * np.sin(0.8 * s + ph[3]), 3.0 * np.sin(0.6 * s + ph[4]),
-                                 4.0 * np.sin(0.5 * s + ph[5])]))
-        T = make_pose(t, r)
+    poses, rng = sequence_poses(n_frames, seed)
+    for T in poses:
         g, d = scene.render(intr, T, invalid_frac, rng)
         yield g, d, T
