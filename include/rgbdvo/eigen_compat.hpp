@@ -46,6 +46,13 @@ struct Vector3d {
   double& operator()(int i) { return v[i]; }
   double operator()(int i) const { return v[i]; }
 };
+struct Vector4d {
+  double v[4] = {0, 0, 0, 0};
+  Vector4d() {}
+  Vector4d(double a, double b, double c, double d) { v[0] = a; v[1] = b; v[2] = c; v[3] = d; }
+  double& operator()(int i) { return v[i]; }
+  double operator()(int i) const { return v[i]; }
+};
 struct Matrix4d {
   double m[16];  // column-major, like Eigen
   double& operator()(int r, int c) { return m[c * 4 + r]; }

@@ -15,12 +15,14 @@ struct KeyPoint {
 class KeypointData {
  public:
   KeyPoint kp;
+  Eigen::Vector4d xyzw;  // homogeneous coordinates (x, y, z, 1), feature.hpp:44-47
   Eigen::Vector3d xyz;
   bool has_depth = true;
   Eigen::Vector2d base_uv;
   Eigen::Vector2d rect_base_uv;
   uint8_t pyramid_level = 0;
   int32_t keypoint_index = 0;
+  int32_t track_id = -1;  // feature.hpp:75: the track this keypoint belongs to (motion_estimate.cpp:380-391), -1 = none
 };
 
 enum MatchStatusCode { MATCH_NEEDS_DEPTH_REFINEMENT, MATCH_REFINEMENT_FAILED, MATCH_OK };
@@ -36,6 +38,7 @@ class FeatureMatch {
   int id = 0;
   double reprojection_error = 0;
   MatchStatusCode status = MATCH_OK;
+  int track_id = -1;  // feature.hpp:297-302
 };
 
 }  // namespace rgbdvo

@@ -50,7 +50,9 @@ class MotionEstimator {
         const int n = info[3];
         std::vector<float> uvs(3 * (size_t)n);
         std::vector<double> rect(2 * (size_t)n), xyz(3 * (size_t)n);
+        std::vector<int32_t> tracks((size_t)n, -1);
         rvo_get_keypoints(ctx_, slot, l, uvs.data(), rect.data(), xyz.data());
+        rvo_get_keypoint_tracks(ctx_, slot, l, tracks.data());
         kps_[s][l].resize(n);
         for (int i = 0; i < n; i++) {
           KeypointData& k = kps_[s][l][i];
@@ -58,13 +60,16 @@ class MotionEstimator {
           k.base_uv = Eigen::Vector2d(k.kp.u * (1 << l), k.kp.v * (1 << l));
           k.rect_base_uv = Eigen::Vector2d(rect[2 * i], rect[2 * i + 1]);
           k.xyz = Eigen::Vector3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
-          k.pyramid_level = (uint8_t)l; k.keypoint_index = i;
+          k.xyzw = Eigen::Vector4d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 1.0);
+          k.pyramid_level = (uint8_t)l; k.keypoint_index = i; k.track_id = tracks[i];
         }
       }
     }
     std::vector<int32_t> ints(7 * (size_t)num_matches_);
     std::vector<double> dbl(8 * (size_t)num_matches_);
+    std::vector<int32_t> mtracks((size_t)num_matches_, -1);
     const int n = rvo_get_matches(ctx_, pair_, num_matches_, ints.data(), dbl.data());
+    rvo_get_match_tracks(ctx_, pair_, num_matches_, mtracks.data());
     for (int m = 0; m < n; m++) {
       const int32_t* a = &ints[7 * m];
       const double* d = &dbl[8 * m];
@@ -76,6 +81,8 @@ class MotionEstimator {
       f.refined_target_keypoint.base_uv = Eigen::Vector2d(d[0] * (1 << a[2]), d[1] * (1 << a[2]));
       f.refined_target_keypoint.rect_base_uv = Eigen::Vector2d(d[2], d[3]);
       f.refined_target_keypoint.xyz = Eigen::Vector3d(d[4], d[5], d[6]);
+      f.refined_target_keypoint.xyzw = Eigen::Vector4d(d[4], d[5], d[6], 1.0);
+      f.track_id = mtracks[m];
       f.status = (MatchStatusCode)a[3]; f.inlier = a[4] != 0; f.in_maximal_clique = f.inlier || d[7] > 0;
       f.id = a[5]; f.compatibility_degree = a[6]; f.reprojection_error = d[7];
     }

@@ -245,6 +245,16 @@ int rvo_get_descriptors(rvo_ctx* ctx, int slot, int level, uint8_t* out /* [n][8
  * are written; returns the number written, or a negative error):
  * ints[n][7] = ref_idx,tgt_idx,level,status,inlier,id,degree; dbl[n][8] = refined u,v, rect u,v, xyz, reproj error */
 int rvo_get_matches(rvo_ctx* ctx, int pair, int cap, int32_t* ints, double* dbl);
+/* FeatureMatch::track_id of the same rows (rgbdvo/feature.hpp:297-302, assigned by motion_estimate.cpp:380-391): a
+ * reference keypoint without a track opens one, the match and the target keypoint take its id, and the target
+ * keypoints of matches that end up as outliers lose theirs again (motion_estimate.cpp:216-222).  A batch of
+ * rvo_match_pairs / rvo_match_frames_dev counts tracks like ONE MotionEstimator working through its pairs in order
+ * (FrameMatcher, fm.hpp:41) as long as no frame slot is used by two pairs of the batch; every stream of
+ * rvo_stream_step has a counter of its own (RGBDVO's estimator, vo.hpp:96).  Returns the number of rows written. */
+int rvo_get_match_tracks(rvo_ctx* ctx, int pair, int cap, int32_t* track_ids);
+/* KeypointData::track_id of the keypoints of a slot's level (rgbdvo/feature.hpp:75; -1 = none, frame.cpp:138), rows as
+ * rvo_get_keypoints writes them.  Returns the number of rows written. */
+int rvo_get_keypoint_tracks(rvo_ctx* ctx, int slot, int level, int32_t* track_ids);
 int rvo_get_lut(rvo_ctx* ctx, float* xmap, float* ymap);
 
 /* Self-test hook (no counterpart in the reference): runs the wave-parallel replay of libstdc++'s std::sort

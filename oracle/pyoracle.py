@@ -201,6 +201,20 @@ class Oracle:
         self.L.orc_get_margins(self.h, _p(out))
         return dict(zip(self.MARGIN_NAMES, out.tolist()))
 
+    def match_tracks(self, n):
+        """track_id of the last EstimateMotion's matches (motion_estimate.cpp:380-391), rows as in matches()."""
+        out = np.zeros(n, np.int32)
+        self.L.orc_get_match_tracks(self.h, C.c_int(n), _p(out))
+        return out
+
+    def keypoint_tracks(self, slot, level):
+        out = np.zeros(self.level_info(slot, level)["num_keypoints"], np.int32)
+        self.L.orc_level_tracks(self.h, C.c_int(slot), C.c_int(level), _p(out))
+        return out
+
+    def num_tracks(self):
+        return int(self.L.orc_num_tracks(self.h))
+
     def matches(self, n):
         ints = np.zeros((n, 7), np.int32)
         dbl = np.zeros((n, 8), np.float64)

@@ -285,6 +285,7 @@ struct KeypointData {  // feature.hpp:34-105
   double rect_base_uv[2]{0, 0};
   uint8_t pyramid_level = 0;
   int32_t keypoint_index = 0;
+  mutable int32_t track_id = -1;  // frame.cpp:138; written through the matches' const pointers (motion_estimate.cpp:380-391)
 };
 
 // ---------------------------------------------------------------- depth
@@ -707,6 +708,7 @@ struct FeatureMatch {  // feature.hpp:210-308
   int id = 0;
   double reprojection_error = 0;
   int status = MATCH_OK;
+  int track_id = -1;
 };
 
 // motion_estimate.cpp:723-755 (exact int32 dot product)
@@ -886,6 +888,7 @@ struct MotionEstimator {
   Frame* ref = nullptr;
   Frame* tgt = nullptr;
   Margins mg;
+  int num_tracks = 0;  // motion_estimate.cpp:116: one counter per MotionEstimator (per RGBDVO / per FrameMatcher)
 
   MotionEstimator(const Camera* c, const Params* p) : cam(c), prm(p) {
     motion.setIdentity();
@@ -1015,6 +1018,13 @@ struct MotionEstimator {
         cam->BilinearLookup(m.refined_target_keypoint.base_uv, m.refined_target_keypoint.rect_base_uv);
         m.status = MATCH_NEEDS_DEPTH_REFINEMENT;
       }
+    }
+    // label matches with their track id, motion_estimate.cpp:380-391
+    for (size_t n = old; n < matches.size(); n++) {
+      FeatureMatch& m = matches[n];
+      if (m.ref_keypoint->track_id < 0) m.ref_keypoint->track_id = num_tracks++;
+      m.target_keypoint->track_id = m.ref_keypoint->track_id;
+      m.track_id = m.ref_keypoint->track_id;
     }
   }
 
@@ -1194,6 +1204,8 @@ struct MotionEstimator {
         m.inlier = false; num_inliers--; num_reprojection_failures++;
       }
     }
+    // no track id travels through an outlier match, motion_estimate.cpp:216-222
+    for (auto& m : matches) if (!m.inlier) m.target_keypoint->track_id = -1;
     refineMotionEstimate();
     computeReprojectionError();
     if (status == SUCCESS) mg.note(&mg.mean_reproj, fabs(mean_reprojection_error - prm->max_mean_reprojection_error));
@@ -1395,6 +1407,7 @@ struct VO {
   Iso pose, ref_to_prev, curr_to_prev, curr_to_ref;
   double curr_to_ref_cov[36];
   bool failed = false;
+  int num_tracks = 0;          // this RGBDVO's MotionEstimator::_num_tracks (the oracle's estimator is shared by all streams)
   bool used_fallback = false;  // this Process() took its estimate from the retry against the previous frame (vo.cpp:131-151)
   VO(Ctx* ctx, int base_slot) : c(ctx) {
     slot_ref = base_slot; slot_prev = base_slot + 1; slot_curr = base_slot + 2;
@@ -1431,7 +1444,9 @@ struct VO {
     Quat q0 = ref_changed ? c->est.EstimateInitialRotation(reff, cur) : c->est.EstimateInitialRotation(prev, cur);
     Iso init = iso_inverse(ref_to_prev);
     iso_rotate(&init, q0);
+    c->est.num_tracks = num_tracks;
     c->est.EstimateMotion(reff, cur, init);
+    num_tracks = c->est.num_tracks;
     if (c->est.status == SUCCESS) {
       Iso to_ref = c->est.motion;
       curr_to_ref = to_ref;
@@ -1442,7 +1457,9 @@ struct VO {
     } else if (!ref_changed) {
       Iso init2; init2.setIdentity();
       iso_rotate(&init2, q0);
+      c->est.num_tracks = num_tracks;
       c->est.EstimateMotion(prev, cur, init2);
+      num_tracks = c->est.num_tracks;
       if (c->est.status == SUCCESS) {
         curr_to_prev = c->est.motion;
         pose = iso_mul(pose, curr_to_prev);
@@ -1586,6 +1603,19 @@ void orc_match_pair(void* cv, int ref_slot, int tgt_slot, PairResult* out) {
   c->est.EstimateMotion(c->slot(ref_slot), c->slot(tgt_slot), init);
   fill_result(c->est, out);
 }
+
+// track ids (motion_estimate.cpp:380-391): of the last EstimateMotion's matches (post-sort order, the rows of
+// orc_get_matches) and of a level's keypoints
+void orc_get_match_tracks(void* cv, int cap, int32_t* out) {
+  Ctx* c = (Ctx*)cv;
+  for (size_t i = 0; i < c->est.matches.size() && (int)i < cap; i++) out[i] = c->est.matches[i].track_id;
+}
+void orc_level_tracks(void* cv, int slot, int level, int32_t* out) {
+  const Level& lv = ((Ctx*)cv)->slot(slot)->levels[level];
+  for (size_t i = 0; i < lv.kps.size(); i++) out[i] = lv.kps[i].track_id;
+}
+int orc_num_tracks(void* cv) { return ((Ctx*)cv)->est.num_tracks; }
+void orc_set_num_tracks(void* cv, int n) { ((Ctx*)cv)->est.num_tracks = n; }
 
 // margins of the last EstimateMotion (struct Margins, 12 doubles in declaration order)
 void orc_get_margins(void* cv, double* out12) {

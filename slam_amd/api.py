@@ -223,6 +223,22 @@ class Context:
             self._chk(rc)
         return ints, dbl
 
+    def match_tracks(self, pair, n):
+        """FeatureMatch::track_id of the rows matches(pair, n) returns (motion_estimate.cpp:380-391)."""
+        out = np.zeros(n, np.int32)
+        rc = self.L.rvo_get_match_tracks(self.h, pair, n, _ptr(out))
+        if rc < 0:
+            self._chk(rc)
+        return out
+
+    def keypoint_tracks(self, slot, level):
+        """KeypointData::track_id of a level's keypoints (-1 = none)."""
+        out = np.zeros(self.level_info(slot, level)["num_keypoints"], np.int32)
+        rc = self.L.rvo_get_keypoint_tracks(self.h, slot, level, _ptr(out))
+        if rc < 0:
+            self._chk(rc)
+        return out
+
     def lut(self):
         x = np.empty((self.H, self.W), np.float32)
         y = np.empty((self.H, self.W), np.float32)

@@ -792,6 +792,7 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
       fb.kp_uvs[kbase + pos] = k;
       fb.kp_src[kbase + pos] = (uint16_t)s;
       fb.kp_rect[kbase + pos] = make_float2(ru, rv);
+      fb.kp_track[kbase + pos] = -1;  // frame.cpp:138: not part of a track yet
       double* xyz = fb.kp_xyz + (kbase + pos) * 3;
       xyz[0] = X; xyz[1] = Y; xyz[2] = Z;
     }

@@ -1214,6 +1214,76 @@ __device__ inline void inverse6(const double* A, double* inv) {
 
 #include "kernels_gn.h"
 
+// ------------------------------------------------------------------ track ids
+// MotionEstimator::matchFeatures labels every match with a track id (motion_estimate.cpp:380-391): a reference keypoint
+// without one opens a new track (`_num_tracks++`, in match order), the target keypoint and the match take the reference
+// keypoint's id; after the reprojection pruning the target keypoints of non-inlier matches lose theirs again
+// (:216-222).  Nothing on the path reads the ids, so they are settled after the estimate in two small launches:
+// k_track_count ranks the new tracks of a pair in match order, k_track_assign turns ranks into ids.
+// mode 0: every pair is a MotionEstimator of its own (the streams: RGBDVO, vo.hpp:96), ctr[pair] is its _num_tracks;
+// mode 1: the batch is one estimator working through the pairs in order (FrameMatcher, fm.hpp:41): ctr_in[0] is
+//         _num_tracks before the batch, ctr_out[0] after it.
+// grid n_pairs, 256 threads.
+__global__ __launch_bounds__(256) void k_track_count(FrameBufs fb, FrameGeom g, PairBufs pb) {
+  __shared__ int s_wave[8];
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  if (!pb.active[pair]) {
+    if (tid == 0) pb.new_tracks[pair] = 0;
+    return;
+  }
+  const int N = pb.n_matches[pair], rs = pb.ref_slot[pair];
+  const size_t mb = (size_t)pair * pb.mcap;
+  int base = 0;
+  for (int c0 = 0; c0 < N; c0 += 256) {
+    const int i = c0 + tid;
+    int cur = 0, flag = 0;
+    if (i < N) {
+      cur = fb.kp_track[(size_t)rs * g.kp_total + g.lv[pb.m_level[mb + i]].kp_off + pb.m_ref[mb + i]];
+      flag = cur < 0;
+    }
+    int total;
+    const int pos = base + block_excl_scan_256(flag, s_wave, &total);
+    if (i < N) pb.m_track[mb + i] = flag ? -2 - pos : cur;  // <= -2: rank of a new track
+    base += total;
+  }
+  if (tid == 0) pb.new_tracks[pair] = base;
+}
+
+__global__ __launch_bounds__(256) void k_track_assign(FrameBufs fb, FrameGeom g, PairBufs pb, int n_pairs, int mode,
+                                                      int32_t* ctr_in, int32_t* ctr_out) {
+  __shared__ int s_wave[8];
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  int base;
+  if (mode == 1) {
+    int before = 0, all = 0;
+    for (int j = tid; j < n_pairs; j += 256) {
+      const int v = pb.new_tracks[j];
+      all += v;
+      if (j < pair) before += v;
+    }
+    int tb, ta;
+    block_excl_scan_256(before, s_wave, &tb);
+    block_excl_scan_256(all, s_wave, &ta);
+    base = ctr_in[0] + tb;
+    if (pair == 0 && tid == 0) ctr_out[0] = ctr_in[0] + ta;
+  } else {
+    base = ctr_in[pair];
+    __syncthreads();
+    if (tid == 0) ctr_out[pair] = base + pb.new_tracks[pair];
+  }
+  if (!pb.active[pair]) return;
+  const int N = pb.n_matches[pair], rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
+  const size_t mb = (size_t)pair * pb.mcap;
+  for (int i = tid; i < N; i += 256) {
+    const int t = pb.m_track[mb + i];
+    const int id = t < -1 ? base + (-2 - t) : t;
+    const int off = g.lv[pb.m_level[mb + i]].kp_off;
+    pb.m_track[mb + i] = id;
+    fb.kp_track[(size_t)rs * g.kp_total + off + pb.m_ref[mb + i]] = id;
+    fb.kp_track[(size_t)ts * g.kp_total + off + pb.m_tgt[mb + i]] = pb.m_inlier[mb + i] ? id : -1;
+  }
+}
+
 // ------------------------------------------------------------------ edge information for the pose graph
 // PoseGraphOptimizer::AddEdge (pose_graph.cpp:254-270): info = edge.covariance.inverse(), one 6x6 partial-pivot
 // inverse per accepted pair.  One thread per pair; pairs without a valid estimate get zeros.

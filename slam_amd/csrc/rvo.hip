@@ -101,6 +101,9 @@ struct rvo_ctx {
   bool ev_p_rec[kPairSets] = {}, ev_t_rec[kPairSets] = {};
   static const int kSlotRing = 8;  // pair-stage completion events of the last eight staged batches (frame slot reuse)
   hipEvent_t ev_pdone[kSlotRing] = {};
+  int32_t* d_track_ctr = nullptr;  // [2 + max_pairs] _num_tracks: [0], [1] alternate for batches that are ONE estimator (mode 1 of
+                                   // k_track_assign), [2 + i] belongs to stream i (mode 0)
+  long long track_batches = 0;     // mode-1 batches so far: the current counter is d_track_ctr[track_batches & 1]
   std::vector<long long> slot_reader;  // [max_frames] last staged batch whose pair stages read the slot (-1: none)
   // profiling
   bool prof = false;
@@ -397,6 +400,7 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
   rc |= dalloc(c, &fb.bk_kp, F * g.total_buckets * g.max_per);
   rc |= dalloc(c, &fb.kp_uvs, F * g.kp_total);
   rc |= dalloc(c, &fb.kp_rect, F * g.kp_total);
+  rc |= dalloc(c, &fb.kp_track, F * g.kp_total);
   rc |= dalloc(c, &fb.kp_xyz, F * g.kp_total * 3);
   rc |= dalloc(c, &fb.kp_desc, F * g.kp_total * RVO_DESC_LEN + 64);
   rc |= dalloc(c, &fb.bk_desc, F * g.kp_total * RVO_DESC_LEN + 64);
@@ -418,6 +422,7 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
     for (size_t i = 0; i < F; i++) itab[i] = fb.img + i * (size_t)g.img_bytes + g.lv[0].img_off;
     HIPCHK(hipMemcpy(fb.l0_tab, itab.data(), F * sizeof(itab[0]), hipMemcpyHostToDevice));
   }
+  HIPCHK(hipMemset(fb.kp_track, 0xFF, F * g.kp_total * 4));  // -1: slots nobody prepared yet
   HIPCHK(hipMemset(fb.kp_cnt, 0, F * RVO_MAX_LEVELS * 4));
   HIPCHK(hipMemset(fb.det_cnt, 0, F * RVO_MAX_LEVELS * 4));
   HIPCHK(hipMemset(fb.grid_cnt, 0, F * RVO_MAX_LEVELS * 4));

@@ -54,6 +54,8 @@ struct FrameBufs {
   uint8_t* kp_desc;   // [slots][kp_total][80]
   uint8_t* bk_desc;   // [slots][total_buckets][max_per][80] descriptors of the grid-filtered keypoints, extracted by
                       // k_fast_grid from its LDS tile; k_descriptors copies the survivors' rows into kp_desc
+  int32_t* kp_track;  // [slots][kp_total] KeypointData::track_id: -1 after Frame::Prepare (frame.cpp:138), then what
+                      // MotionEstimator::matchFeatures / EstimateMotion leave (motion_estimate.cpp:216-222, 380-391)
   uint16_t* kp_src;   // [slots][kp_total] level-local bucket slot (bucket * max_per + j) each kept keypoint came from
   int32_t* kp_cnt;    // [slots][RVO_MAX_LEVELS]
   int32_t* det_cnt;   // [slots][RVO_MAX_LEVELS] FAST corners after NMS (adaptive threshold input)
@@ -86,6 +88,8 @@ struct PairBufs {
   int32_t* m_degree;   // [pairs][mcap]
   uint8_t* m_inlier;   // [pairs][mcap] indexed by id
   double* m_reproj;    // [pairs][mcap] indexed by id
+  int32_t* m_track;    // [pairs][mcap] FeatureMatch::track_id, indexed by id
+  int32_t* new_tracks; // [pairs] tracks the pair's EstimateMotion opened (reference keypoints that had none)
   uint32_t* order;     // [pairs][mcap] sorted keys degree<<16|id
   uint32_t* cbits;     // [pairs][mcap][cwords] consistency bit matrix
   rvo_pair_result* result;  // [pairs]

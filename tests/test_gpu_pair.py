@@ -283,3 +283,44 @@ def test_staged_pipeline_in_one_context_equals_a_context_working_alone(scene, in
     ctx.match_frames_dev(batches[1][0].data_ptr(), batches[1][1].data_ptr(), 20, slots)
     assert key(ctx.pair_results(n)) == alone[1]
     pipe.close()
+
+
+def test_track_ids_of_a_batch_equal_one_estimator_working_through_the_pairs(scene, intr640):
+    """motion_estimate.cpp:380-391 / 216-222: FeatureMatch::track_id and KeypointData::track_id.  A batch counts tracks
+    like ONE MotionEstimator (FrameMatcher's, fm.hpp:41) that is handed its pairs in order; matching the same prepared
+    frames again reuses the ids the reference keypoints already carry."""
+    from oracle.pyoracle import Oracle, default_params as odef
+    from slam_amd.api import Context, default_params
+    n = 5
+    pairs = [synth.make_pair(900 + i, intr640, scene, invalid_frac=0.1 * (i % 2)) for i in range(n)]
+    gray = np.stack([pairs[i][j] for i in range(n) for j in (0, 2)])
+    depth = np.stack([pairs[i][j] for i in range(n) for j in (1, 3)])
+    slots = np.arange(2 * n, dtype=np.int32)
+    ctx = Context(intr640, default_params(frame_matcher=True), max_frames=2 * n, max_pairs=n)
+    orc = Oracle(intr640, odef(frame_matcher=True))
+    ctx.prepare_frames(gray, depth, 20, slots)
+    for s in range(2 * n):
+        orc.prepare(s, gray[s], depth[s], 20)
+    for rnd in range(2):  # second round: the same frames again, ids are already on the keypoints
+        res = ctx.match_pairs(slots[0::2], slots[1::2])
+        for i in range(n):
+            ro = orc.match_pair(2 * i, 2 * i + 1)
+            N = ro["num_matches"]
+            assert res[i]["num_matches"] == N and N > 300
+            tg, to = ctx.match_tracks(i, N), orc.match_tracks(N)
+            assert np.array_equal(tg, to), (rnd, i)
+            assert to.min() >= 0 and len(set(to.tolist())) == N  # one track per match
+            for lvl in range(3):
+                for s in (2 * i, 2 * i + 1):
+                    assert np.array_equal(ctx.keypoint_tracks(s, lvl), orc.keypoint_tracks(s, lvl)), (rnd, i, s, lvl)
+            ig, _ = ctx.matches(i, N)
+            tgt_tr = ctx.keypoint_tracks(2 * i + 1, 0)
+            lv0 = ig[:, 2] == 0
+            inl = ig[:, 4] == 1
+            assert np.array_equal(tgt_tr[ig[lv0 & inl, 1]], tg[lv0 & inl])       # inliers hand their id to the target keypoint
+            assert (tgt_tr[ig[lv0 & ~inl, 1]] == -1).all()                       # outliers do not
+        if rnd == 0:
+            first_total = orc.num_tracks()
+            assert first_total == sum(r["num_matches"] for r in res)            # pair i starts where pair i-1 stopped
+    assert orc.num_tracks() >= first_total
+    ctx.close()

@@ -21,6 +21,7 @@ def test_streams_vs_oracle(scene, intr640):
     seqs = [list(synth.make_sequence(n_frames, seed=s, intr=intr640, scene=scene,
                                      invalid_frac=0.1 if s == 1 else 0.0)) for s in range(n_streams)]
     first_pose = [None] * n_streams
+    tracks_seen = [0] * n_streams
     for f in range(n_frames):
         gray = np.stack([seqs[s][f][0] for s in range(n_streams)])
         depth = np.stack([seqs[s][f][1] for s in range(n_streams)])
@@ -36,12 +37,20 @@ def test_streams_vs_oracle(scene, intr640):
                 assert rg["status"] == ro["status"]
             assert np.abs(rg["pose"] - ro["pose"]).max() < 1e-8, (f, s)
             assert np.abs(rg["curr_to_ref"] - ro["curr_to_ref"]).max() < 1e-8, (f, s)
+            if ro["rc"] == 1 and f >= warm:
+                # track ids (motion_estimate.cpp:380-391): every stream's estimator counts its own tracks; ids travel from
+                # frame to frame through the reference keypoints
+                n = ro["num_matches"]
+                assert np.array_equal(vo.ctx.match_tracks(s, n), orcs[s].match_tracks(n)), (f, s)
+                tracks_seen[s] = max(tracks_seen[s], int(orcs[s].match_tracks(n).max(initial=-1)) + 1)
+                assert orcs[s].num_tracks() >= tracks_seen[s]
             if f == warm - 1:
                 first_pose[s] = seqs[s][f][2]
     # accuracy vs ground truth: pose_ integrates motion relative to the first processed frame
     for s in range(n_streams):
         T_gt = np.linalg.inv(first_pose[s]) @ seqs[s][-1][2]
         assert np.abs(res[s]["pose"] - T_gt[:3]).max() < 5e-3
+        assert tracks_seen[s] > 500  # tracks were opened, and ids of later frames continue earlier ones
     for v in ovos:
         v.close()
 
