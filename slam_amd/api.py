@@ -381,7 +381,8 @@ class PipelinedFrameMatcher:
             contexts = depth
         self.n_pairs = n_pairs
         p = params or default_params(frame_matcher=True)
-        self.staged = contexts == 1
+        # RVO_STAGED=0 with one context: one chain per batch, nothing overlaps (tools/alone_times.py)
+        self.staged = contexts == 1 and os.environ.get("RVO_STAGED", "1") != "0"
         if self.staged:
             nsets = int(os.environ.get("RVO_SLOT_SETS", "5"))  # frame-slot sets consecutive batches rotate through
             self.ctxs = [Context(intr, p, max_frames=2 * nsets * n_pairs, max_pairs=n_pairs, device=device)]
