@@ -930,9 +930,11 @@ __global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) 
 
 // ------------------------------------------------------------------ sort + greedy clique
 // grid (n_pairs), CLIQUE_WAVES*64 threads; dynamic LDS = clique_lds_bytes(mcap, cwords).  All waves sort; wave 0
-// then walks the sorted candidates (8 waves measured best).
+// then walks the sorted candidates.  8 waves are fastest alone; inside the staged pipeline 4 are (305 k against 298 k
+// pairs/s; 2 waves: 300 k): a 512-thread workgroup at 185 VGPRs needs two free wave slots on all four SIMDs of a CU at
+// once and waits long for them beside k_fast_grid (0.107 ms alone, 0.42 ms in the pipeline).
 #ifndef CLIQUE_WAVES
-#define CLIQUE_WAVES 8
+#define CLIQUE_WAVES 4
 #endif
 __host__ __device__ inline int clique_ctl_ints() { return 4 + SORT_QCAP * 2 + CLIQUE_WAVES * SORT_STACK * 2; }
 // keys | accepted mask | sort control | scratch: the sort's 12*mcap bytes, reused as the 64 x (cwords+1) staged rows
