@@ -200,7 +200,10 @@ __device__ inline void block_sum_lds(double* v, double* s_big) {
 // ------------------------------------------------------------------ initial rotation
 // grid (n_pairs), 256 threads, dynamic LDS = 5 * npx floats + 64 doubles.
 // mode 0: write q0 only; mode 1: also init_pose = Identity.rotate(q0) (fm.cpp:41-47).
-__global__ __launch_bounds__(256) void k_init_rotation(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, int mode) {
+#ifndef ROT_MIN_WAVES
+#define ROT_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, int mode) {
   RVO_OCC_SCOPE(5, 1);
   extern __shared__ __align__(16) uint8_t lds[];
   const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x;
@@ -373,7 +376,10 @@ __device__ inline uint32_t sad80(const uint8_t* a, const uint8_t* b) {
 // (feature.cpp:6301-6308).
 __host__ __device__ inline int match_max_runs(int cap) { return (cap + 63) / 64 + 1; }
 __host__ __device__ inline int match_lds_bytes(int cap) { return cap * 16 + match_max_runs(cap) * 16 + MATCH_WAVES * MATCH_QCAP * 4 + 128; }
-__global__ __launch_bounds__(MATCH_THREADS) void k_match(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, EstParams ep) {
+#ifndef MATCH_MIN_WAVES
+#define MATCH_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(MATCH_THREADS, MATCH_MIN_WAVES) void k_match(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, EstParams ep) {
   RVO_OCC_SCOPE(6, 1);
   extern __shared__ __align__(16) uint8_t lds[];
   const int lvl = blockIdx.x, pair = blockIdx.y + pb.pair0, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -563,7 +569,10 @@ __device__ inline int group16_sum(int v) {
 #define REFINE_WIN_PITCH 20
 // grid (ceil(kp_total/16), n_pairs), 256 threads: 16 lanes per match, 5 descriptor taps per lane; all sums are exact
 // int32, so the lane split does not change any value.  Branches below are uniform within a 16-lane group.
-__global__ __launch_bounds__(256) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
+#ifndef REFINE_MIN_WAVES
+#define REFINE_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, REFINE_MIN_WAVES) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
   RVO_OCC_SCOPE(7, 16);
   int bx, py;  // XCD-aware: the workgroups of a pair run on one XCD, whose L2 then holds the pair's two images once
   xcd_map(gridDim.x, gridDim.y, blockIdx.x, blockIdx.y, &bx, &py);
@@ -820,7 +829,10 @@ __global__ __launch_bounds__(256) void k_refine_finish(FrameBufs fb, FrameGeom g
 // both ends is repeated in fp64 exactly as the reference does it (Eigen 3.2: sqrt(x*x + (y*y + z*z))).  A NaN
 // coordinate (depth.cpp:137-147 quirk) makes the reference's comparison false; the fp32 test classifies it as false too.
 typedef float f2_t __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(256) void k_consistency(PairBufs pb, EstParams ep) {
+#ifndef CONS_MIN_WAVES
+#define CONS_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, CONS_MIN_WAVES) void k_consistency(PairBufs pb, EstParams ep) {
   RVO_OCC_SCOPE(9, 4);
   __shared__ float s_c[(CONS_TILE + 32) * 6];
   const int pair = blockIdx.y + pb.pair0;
