@@ -198,6 +198,16 @@ int rvo_initial_rotation(rvo_ctx* ctx, int n, const int32_t* prev_slots, const i
  * slots [3*s, 3*s+3).  rvo_streams_reset = constructor + SetInitPose(identity) (rgbdvo/vo.hpp:42-45). */
 int rvo_streams_reset(rvo_ctx* ctx, int n_streams);
 int rvo_stream_step(rvo_ctx* ctx, int n_streams, const uint8_t* gray, const uint16_t* depth, rvo_stream_result* out);
+/* No counterpart in the reference (its ProcessFrame takes host pointers and blocks, rgbdvo/vo.cpp:55): the same step
+ * for hosts that keep frames coming.  The images are uploaded by a copy stream into one of two device staging sets, the
+ * step waits for that upload only, and the call returns when everything is enqueued; results with
+ * rvo_get_stream_results (or rvo_streams_record).  With page-locked host buffers (rvo_host_alloc) the upload of step
+ * k+1 runs beside the kernels of step k.  The host buffers may be overwritten after rvo_wait_upload returns. */
+int rvo_stream_step_host_async(rvo_ctx* ctx, int n_streams, const uint8_t* gray, const uint16_t* depth);
+int rvo_wait_upload(rvo_ctx* ctx);
+/* Page-locked host memory for image buffers (hipHostMalloc / hipHostFree). */
+int rvo_host_alloc(size_t bytes, void** out);
+int rvo_host_free(void* p);
 int rvo_stream_step_dev(rvo_ctx* ctx, int n_streams, const uint8_t* gray_dev, const uint16_t* depth_dev);
 int rvo_get_stream_results(rvo_ctx* ctx, int n_streams, rvo_stream_result* out);
 /* Frame slots stream `stream` currently holds: out[3] = reference, previous, current frame

@@ -256,6 +256,15 @@ class Context:
         self._chk(self.L.rvo_stream_step(self.h, n_streams, _ptr(gray), _ptr(depth), out))
         return [stream_result_to_dict(r) for r in out]
 
+    def stream_step_host_async(self, gray, depth, n_streams):
+        """rvo_stream_step_host_async: returns once the step is enqueued; gray / depth (ideally from host_array) must stay
+        untouched until wait_upload()."""
+        assert gray.dtype == np.uint8 and depth.dtype == np.uint16 and gray.flags.c_contiguous and depth.flags.c_contiguous
+        self._chk(self.L.rvo_stream_step_host_async(self.h, n_streams, _ptr(gray), _ptr(depth)))
+
+    def wait_upload(self):
+        self._chk(self.L.rvo_wait_upload(self.h))
+
     def stream_step_dev(self, gray_ptr: int, depth_ptr: int, n_streams):
         self._chk(self.L.rvo_stream_step_dev(self.h, n_streams, C.c_void_p(gray_ptr), C.c_void_p(depth_ptr)))
 
@@ -362,6 +371,32 @@ class FrameMatcher:
             m[:3] = r["pose"]
             out.append((int(target_ids[k]), r["status"] == 1, m, r["cov"], info[k]))
         return out
+
+
+class HostArray:
+    """A numpy array in page-locked host memory (rvo_host_alloc); free() or drop the last reference."""
+
+    def __init__(self, shape, dtype):
+        self.L = _lib.load()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        rc = self.L.rvo_host_alloc(n, C.byref(p))
+        if rc != 0:
+            raise RuntimeError(f"rvo_host_alloc: {rc}")
+        self.ptr = p
+        self.array = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p.value)).view(dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.L.rvo_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class PipelinedFrameMatcher:

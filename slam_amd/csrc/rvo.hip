@@ -62,6 +62,14 @@ struct rvo_ctx {
   uint8_t* d_gray_stage = nullptr;
   uint16_t* d_depth_stage = nullptr;
   size_t stage_frames = 0;
+  // rvo_stream_step_host_async: two staging sets filled by a copy stream while the previous step computes
+  uint8_t* d_gray_db[2] = {nullptr, nullptr};
+  uint16_t* d_depth_db[2] = {nullptr, nullptr};
+  size_t db_frames = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
+  bool ev_used_rec[2] = {false, false};
+  int db_flip = 0;
   // streams
   StreamState* d_streams = nullptr;
   rvo_stream_result* d_stream_res = nullptr;
@@ -457,6 +465,13 @@ void rvo_destroy(rvo_ctx* c) {
   for (int i = 0; i < rvo_ctx::kRing; i++) if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
   if (c->d_gray_stage) (void)hipFree(c->d_gray_stage);
   if (c->d_depth_stage) (void)hipFree(c->d_depth_stage);
+  for (int i = 0; i < 2; i++) {
+    if (c->d_gray_db[i]) (void)hipFree(c->d_gray_db[i]);
+    if (c->d_depth_db[i]) (void)hipFree(c->d_depth_db[i]);
+    if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
+    if (c->ev_used[i]) (void)hipEventDestroy(c->ev_used[i]);
+  }
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   for (int i = 0; i < rvo_ctx::kAux; i++) {
     if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);

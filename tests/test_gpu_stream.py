@@ -223,3 +223,40 @@ def test_device_side_trajectories_and_world1_gather(scene, intr640):
     uid = RcclComm.unique_id()
     assert len(uid) == 128 and any(uid)
     ctx.close()
+
+
+def test_stream_step_host_async_equals_blocking_step(scene, intr640):
+    """rvo_stream_step_host_async (double-buffered upload on a copy stream, returns when enqueued) gives the same stream
+    results as the blocking rvo_stream_step, from pinned (rvo_host_alloc) and from pageable host buffers."""
+    from slam_amd.api import HostArray, RGBDVOStreams, default_params
+    n_streams, n_frames = 4, 7
+    seqs = [list(synth.make_sequence(n_frames, seed=20 + s, intr=intr640, scene=scene)) for s in range(n_streams)]
+    ref = RGBDVOStreams(intr640, n_streams, params=default_params(warmup_frames=1))
+    expect = []
+    for f in range(n_frames):
+        expect.append(ref.ProcessFrame(np.stack([seqs[s][f][0] for s in range(n_streams)]),
+                                       np.stack([seqs[s][f][1] for s in range(n_streams)])))
+    ref.ctx.close()
+    for pinned in (True, False):
+        vo = RGBDVOStreams(intr640, n_streams, params=default_params(warmup_frames=1))
+        if pinned:  # two host buffer sets, refilled while the previous step computes
+            hg = [HostArray((n_streams, 480, 640), np.uint8) for _ in range(2)]
+            hd = [HostArray((n_streams, 480, 640), np.uint16) for _ in range(2)]
+        for f in range(n_frames):
+            g = np.stack([seqs[s][f][0] for s in range(n_streams)])
+            d = np.stack([seqs[s][f][1] for s in range(n_streams)])
+            if pinned:
+                hg[f & 1].array[...] = g
+                hd[f & 1].array[...] = d
+                g, d = hg[f & 1].array, hd[f & 1].array
+            vo.ctx.stream_step_host_async(g, d, n_streams)
+            vo.ctx.wait_upload()  # g, d may be reused
+            got = vo.ctx.stream_results(n_streams)
+            for s in range(n_streams):
+                for k in ("rc", "status", "num_matches", "num_inliers", "fast_thr", "keyframe_changed"):
+                    assert got[s][k] == expect[f][s][k], (pinned, f, s, k)
+                assert np.array_equal(got[s]["pose"], expect[f][s]["pose"]), (pinned, f, s)
+        vo.ctx.close()
+        if pinned:
+            for h in hg + hd:
+                h.free()

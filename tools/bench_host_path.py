@@ -26,4 +26,21 @@ for kind in ("pageable", "pinned"):
     dt = (time.perf_counter() - t0) / steps
     mb = (g.nbytes + d.nbytes) / 1e6
     print(f"{kind:9s}: {dt * 1e3:.2f} ms per step of {n} frames = {n / dt:.0f} frames/s, {mb / dt / 1e3:.1f} GB/s of images; ok {sum(x['status'] == 1 for x in r)}", flush=True)
+    if kind == "pinned":  # uploads of step k+1 beside the kernels of step k: two pinned sets, no result read-back per step
+        from slam_amd.api import HostArray
+        hg = [HostArray(g.shape, np.uint8) for _ in range(2)]
+        hd = [HostArray(d.shape, np.uint16) for _ in range(2)]
+        for i in range(2):
+            hg[i].array[...] = g
+            hd[i].array[...] = d
+        for k in range(3):
+            vo.ctx.stream_step_host_async(hg[k & 1].array, hd[k & 1].array, n)
+        vo.ctx.sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            vo.ctx.stream_step_host_async(hg[k & 1].array, hd[k & 1].array, n)
+        vo.ctx.sync()
+        dt = (time.perf_counter() - t0) / steps
+        r = vo.ctx.stream_results(n)
+        print(f"pinned, rvo_stream_step_host_async: {dt * 1e3:.2f} ms per step = {n / dt:.0f} frames/s, {mb / dt / 1e3:.1f} GB/s; ok {sum(x['status'] == 1 for x in r)}", flush=True)
     vo.ctx.close()
