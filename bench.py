@@ -207,6 +207,16 @@ def main():
     if not noprof:
         wp = read_prof()
         dom = max(wp, key=lambda k: wp[k]["total_ms"]) if wp else None
+        # Inside the pipeline every launch is stretched by whatever runs beside it (k_refine: 0.15 ms alone, 0.5 ms here),
+        # so "dominant" is decided by the work a kernel does, not by how long it was resident: the largest VALU issue
+        # time per batch in the committed SQ counters of this command, if that file is there
+        sp0 = os.path.join(ROOT, "profiles", "r02_sq_counters.csv")
+        if wp and os.path.exists(sp0):
+            import csv
+            issue = {r["kernel"]: float(r["valu_issue_ms_at_2.4GHz"]) * int(r["launches_per_batch"]) for r in csv.DictReader(open(sp0))}
+            cand = [k for k in wp if k in issue]
+            if cand:
+                dom = max(cand, key=lambda k: issue[k])
         for c in ctxs:
             c.profile_enable(dom is not None, only=dom)  # also clears the accumulated records
 
@@ -300,9 +310,9 @@ def main():
                         frac=ach / HBM_PEAK, traffic=traffic, traffic_source=traffic_src, avg_launch_ms=avg_s * 1e3,
                         launches_timed=prof_dom[dom]["calls"],
                         algorithmic_bytes_per_launch=B[dom],
-                        note="launch = one whole batch (512 frames / 256 pairs); launches of two batches in flight overlap, "
-                             "so a launch's duration includes contention; the kernel is VALU-bound, not HBM-bound "
-                             "(DESIGN.md section 5)")
+                        note="launch = one whole batch (512 frames / 256 pairs); the launches of four batches are in flight at a time, "
+                             "so a launch's duration includes contention (0.33 ms alone); the kernel is VALU-bound, not "
+                             "HBM-bound (DESIGN.md section 5); dominant = largest VALU issue time per batch")
         # VALU issue roofline (the bound that actually holds for this path): issue time per batch from
         # the committed SQ counters of this same command (a --pmc pass of its own) against the live batch time
         roof_valu = None
