@@ -324,3 +324,56 @@ def test_track_ids_of_a_batch_equal_one_estimator_working_through_the_pairs(scen
             assert first_total == sum(r["num_matches"] for r in res)            # pair i starts where pair i-1 stopped
     assert orc.num_tracks() >= first_total
     ctx.close()
+
+
+def test_staged_pipeline_ragged_batches_and_mixed_entry_points(scene, intr640):
+    """Batches of different sizes (1, 19, 40, 7 pairs) back to back through the staged pipeline, on the same slots, then
+    the other entry points of the same context (rvo_match_pairs on the frames already prepared, rvo_get_pair_information,
+    a stream step): every result equals what a fresh context computes for that batch alone."""
+    import torch
+    from slam_amd.api import Context, default_params
+    cap = 40
+    pairs = [synth.make_pair(1200 + i, intr640, scene, invalid_frac=0.1 * (i % 3 == 0)) for i in range(6)]
+    gray = np.stack([pairs[i % 6][j] for i in range(cap) for j in (0, 2)])
+    depth = np.stack([pairs[i % 6][j] for i in range(cap) for j in (1, 3)])
+    dg = torch.from_numpy(gray).cuda()
+    dd = torch.from_numpy(depth.view(np.int16)).cuda()
+    torch.cuda.synchronize()
+
+    def key(res):
+        return [(r["status"], r["num_matches"], r["num_inliers"], r["pose"].tobytes(), r["cov"].tobytes()) for r in res]
+
+    sizes = [1, 19, 40, 7]
+    alone = {}
+    for n in set(sizes):
+        c = Context(intr640, default_params(frame_matcher=True), max_frames=2 * cap, max_pairs=cap)
+        c.set_pipeline(False)
+        c.match_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, np.arange(2 * n, dtype=np.int32))
+        alone[n] = key(c.pair_results(n))
+        c.close()
+    ctx = Context(intr640, default_params(frame_matcher=True), max_frames=3 * cap, max_pairs=cap)  # staged by default
+    from slam_amd.api import PairResult, pair_result_to_dict
+    for rep in range(2):
+        for n in sizes:
+            ctx.match_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, np.arange(2 * n, dtype=np.int32))  # same slots every time
+        out = (PairResult * sizes[-1])()
+        ctx._chk(ctx.L.rvo_get_batch_results(ctx.h, 0, sizes[-1], out))
+        assert key([pair_result_to_dict(r) for r in out]) == alone[sizes[-1]]
+        out = (PairResult * sizes[-2])()
+        ctx._chk(ctx.L.rvo_get_batch_results(ctx.h, 1, sizes[-2], out))
+        assert key([pair_result_to_dict(r) for r in out]) == alone[sizes[-2]]
+    # the frames of the last batch are still prepared in slots 0..13: match them again through rvo_match_pairs
+    n = sizes[-1]
+    res = ctx.match_pairs(np.arange(0, 2 * n, 2), np.arange(1, 2 * n, 2))
+    assert key(res) == alone[n]
+    info = ctx.pair_information(n)
+    for i in range(n):
+        if res[i]["status"] == 1:
+            np.testing.assert_allclose(info[i] @ res[i]["cov"], np.eye(6), atol=1e-6)
+    # zero pairs is a no-op, a batch beyond max_pairs an error; neither disturbs the pipeline
+    ctx.match_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, np.zeros(0, np.int32))
+    with pytest.raises(Exception):
+        ctx.match_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, np.arange(2 * (cap + 1), dtype=np.int32))
+    ctx.match_frames_dev(dg.data_ptr(), dd.data_ptr(), 20, np.arange(2 * 19, dtype=np.int32))
+    assert key(ctx.pair_results(19)) == alone[19]
+    ctx.close()
