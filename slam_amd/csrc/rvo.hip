@@ -107,7 +107,7 @@ struct rvo_ctx {
   int staged_pending = 0;        // bit s: set s has staged work the main stream has not been ordered after yet
   hipEvent_t ev_f[kPairSets] = {}, ev_p[kPairSets] = {}, ev_t[kPairSets] = {}, ev_pyr2[kPairSets] = {}, ev_rot2[kPairSets] = {};
   bool ev_p_rec[kPairSets] = {}, ev_t_rec[kPairSets] = {};
-  static const int kSlotRing = 8;  // pair-stage completion events of the last eight staged batches (frame slot reuse)
+  static const int kSlotRing = 8;  // tail completion events of the last eight staged batches (frame slot reuse)
   hipEvent_t ev_pdone[kSlotRing] = {};
   int32_t* d_track_ctr = nullptr;  // [2 + max_pairs] _num_tracks: [0], [1] alternate for batches that are ONE estimator (mode 1 of
                                    // k_track_assign), [2 + i] belongs to stream i (mode 0)
@@ -510,12 +510,12 @@ static int join_staged(rvo_ctx* c) {
     if (rcj_) return rcj_;                                            \
     HIPCHK(hipStreamSynchronize((c)->stream));                        \
   } while (0)
-// Frame slots about to be rewritten on stream st: wait for the pair stages of the staged batches that still read them.
+// Frame slots about to be rewritten on stream st: wait for the tail of the staged batches that still use them.
 static int wait_slots_free(rvo_ctx* c, hipStream_t st, int n, const int32_t* slots) {
   long long need = -1;
   for (int i = 0; i < n; i++) need = std::max(need, c->slot_reader[slots[i]]);
   if (need < 0) return RVO_OK;
-  // events exist for the last kSlotRing batches; an older batch's pair stages precede theirs on the pair stream
+  // events exist for the last kSlotRing batches; an older batch's tail precedes theirs on the tail stream
   const long long b = std::max(need, c->batch_id - rvo_ctx::kSlotRing);
   if (b >= 0 && b < c->batch_id) HIPCHK(hipStreamWaitEvent(st, c->ev_pdone[b % rvo_ctx::kSlotRing], 0));
   return RVO_OK;

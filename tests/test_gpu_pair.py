@@ -251,7 +251,7 @@ def test_staged_pipeline_in_one_context_equals_a_context_working_alone(scene, in
     def key(res):
         return [(r["status"], r["num_matches"], r["num_inliers"], r["pose"].tobytes(), r["cov"].tobytes()) for r in res]
 
-    alone, alone_matches = [], []
+    alone, alone_matches, alone_tracks = [], [], []
     for dg, dd in batches:
         c = Context(intr640, default_params(frame_matcher=True), max_frames=2 * n, max_pairs=n)
         c.set_pipeline(False)
@@ -259,6 +259,7 @@ def test_staged_pipeline_in_one_context_equals_a_context_working_alone(scene, in
         res = c.pair_results(n)
         alone.append(key(res))
         alone_matches.append(c.matches(n - 1, res[n - 1]["num_matches"]))
+        alone_tracks.append(c.match_tracks(n - 1, res[n - 1]["num_matches"]))
         c.close()
     pipe = PipelinedFrameMatcher(intr640, n, contexts=1)
     assert len(pipe.slot_sets) == slot_sets
@@ -270,6 +271,11 @@ def test_staged_pipeline_in_one_context_equals_a_context_working_alone(scene, in
     ctx = pipe.ctxs[0]
     im, dm = ctx.matches(n - 1, alone[7 % 3][n - 1][1])
     assert np.array_equal(im, alone_matches[7 % 3][0]) and np.array_equal(dm, alone_matches[7 % 3][1], equal_nan=True)
+    # track ids: the context has counted the tracks of eight batches, the lone context those of one; the frames were
+    # fresh both times (also with ONE set of slots, where the next batch's frame stages must not reset the keypoints'
+    # ids before this batch's tail has written them), so the ids differ by a constant
+    tr = ctx.match_tracks(n - 1, alone[7 % 3][n - 1][1])
+    assert np.array_equal(tr - tr.min(), alone_tracks[7 % 3] - alone_tracks[7 % 3].min()) and tr.min() > 7 * 30000
     # given initial poses (no EstimateInitialRotation on the R stream), then back to one chain per call in the same context
     res_alone = None
     init = np.tile(np.eye(4)[:3].reshape(1, 12), (n, 1))
