@@ -567,19 +567,24 @@ __device__ inline int group16_sum(int v) {
 #define REFINE_TAPS (RVO_DESC_LEN / REFINE_GROUP)  // 5 taps per lane
 #define REFINE_WIN_ROWS 16
 #define REFINE_WIN_PITCH 20
-// grid (ceil(kp_total/16), n_pairs), 256 threads: 16 lanes per match, 5 descriptor taps per lane; all sums are exact
+// grid (ceil(kp_total/8), n_pairs), REFINE_THREADS threads: 16 lanes per match, 5 descriptor taps per lane; all sums are exact
 // int32, so the lane split does not change any value.  Branches below are uniform within a 16-lane group.
 #ifndef REFINE_MIN_WAVES
 #define REFINE_MIN_WAVES 1
 #endif
-__global__ __launch_bounds__(256, REFINE_MIN_WAVES) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
+// 8 matches per workgroup: alone the size does not matter (matches are independent), inside the pipeline a two-wave
+// workgroup finds room beside k_fast_grid sooner than a four-wave one (311 k against 305 k pairs/s; 64 threads: 309 k)
+#ifndef REFINE_THREADS
+#define REFINE_THREADS 128
+#endif
+__global__ __launch_bounds__(REFINE_THREADS, REFINE_MIN_WAVES) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
   RVO_OCC_SCOPE(7, 16);
   int bx, py;  // XCD-aware: the workgroups of a pair run on one XCD, whose L2 then holds the pair's two images once
   xcd_map(gridDim.x, gridDim.y, blockIdx.x, blockIdx.y, &bx, &py);
   const int pair = py + pb.pair0;
   if (!pb.active[pair]) return;
   const int gl = threadIdx.x & (REFINE_GROUP - 1);
-  const int i_grp = bx * (256 / REFINE_GROUP) + (threadIdx.x / REFINE_GROUP);
+  const int i_grp = bx * (REFINE_THREADS / REFINE_GROUP) + (threadIdx.x / REFINE_GROUP);
   int off[RVO_MAX_LEVELS + 1];
   off[0] = 0;
   for (int l = 0; l < g.levels; l++) off[l + 1] = off[l] + pb.lm_cnt[pair * RVO_MAX_LEVELS + l];
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(256, REFINE_MIN_WAVES) void k_refine(FrameBufs fb, 
   const int rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
   // 16x16 target window around the matched keypoint (rows of 5 aligned dwords): positions within +-3 px of it, i.e.
   // practically every ESM step, read their 10x10 taps from LDS instead of paying an L2 round trip per iteration
-  __shared__ __align__(4) uint8_t s_win[256 / REFINE_GROUP][REFINE_WIN_ROWS * REFINE_WIN_PITCH];
+  __shared__ __align__(4) uint8_t s_win[REFINE_THREADS / REFINE_GROUP][REFINE_WIN_ROWS * REFINE_WIN_PITCH];
   if (i_grp < N) {
   const int i = i_grp;
   int lvl = 0;
@@ -734,12 +739,15 @@ __global__ __launch_bounds__(256, REFINE_MIN_WAVES) void k_refine(FrameBufs fb, 
 
 // Gating + refined record, motion_estimate.cpp:360-376: one thread per match (a kernel of its own so that its fp64
 // lookups do not add to the register budget of the ESM loop above).  grid (ceil(mcap/256), n_pairs), 256 threads.
-__global__ __launch_bounds__(256) void k_refine_finish(FrameBufs fb, FrameGeom g, PairBufs pb) {
+#ifndef FINISH_THREADS
+#define FINISH_THREADS 256
+#endif
+__global__ __launch_bounds__(FINISH_THREADS) void k_refine_finish(FrameBufs fb, FrameGeom g, PairBufs pb) {
   RVO_OCC_SCOPE(8, 4);
   const int pair = blockIdx.y + pb.pair0;
   if (!pb.active[pair]) return;
   const int N = pb.n_matches[pair];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * FINISH_THREADS + threadIdx.x;
   if (i >= N) return;
   const size_t mi0 = (size_t)pair * pb.mcap + i;
   const int lvl = pb.m_level[mi0];
@@ -832,7 +840,13 @@ typedef float f2_t __attribute__((ext_vector_type(2)));
 #ifndef CONS_MIN_WAVES
 #define CONS_MIN_WAVES 1
 #endif
-__global__ __launch_bounds__(256, CONS_MIN_WAVES) void k_consistency(PairBufs pb, EstParams ep) {
+// CONS_THREADS rows of a 256 x 256 tile per workgroup (256 / CONS_THREADS workgroups per tile): the waves of a tile
+// work independently once the columns are staged, and small workgroups are placed sooner beside k_fast_grid
+#ifndef CONS_THREADS
+#define CONS_THREADS 256
+#endif
+#define CONS_PARTS (256 / CONS_THREADS)
+__global__ __launch_bounds__(CONS_THREADS, CONS_MIN_WAVES) void k_consistency(PairBufs pb, EstParams ep) {
   RVO_OCC_SCOPE(9, 4);
   __shared__ float s_c[(CONS_TILE + 32) * 6];
   const int pair = blockIdx.y + pb.pair0;
@@ -841,15 +855,16 @@ __global__ __launch_bounds__(256, CONS_MIN_WAVES) void k_consistency(PairBufs pb
   // blockIdx.x enumerates the tile pairs (I, J >= I) of the upper triangle, row tile by row tile: equal work per workgroup
   // and several times more workgroups than CUs (one workgroup per row tile left the CUs with uneven column counts)
   const int T = (pb.mcap + 255) / 256;
-  int tj = blockIdx.x, ti = 0;
+  const int part = blockIdx.x % CONS_PARTS;
+  int tj = blockIdx.x / CONS_PARTS, ti = 0;
   while (tj >= T - ti) { tj -= T - ti; ti++; }
   tj += ti;
   const int jstart = ti * 256, jcol = tj * 256;
   if (jcol >= N) return;  // (jstart <= jcol)
-  for (int k = threadIdx.x; k < (CONS_TILE + 32) * 6; k += 256) s_c[k] = 0.f;  // padding columns stay finite
+  for (int k = threadIdx.x; k < (CONS_TILE + 32) * 6; k += CONS_THREADS) s_c[k] = 0.f;  // padding columns stay finite
   const int lane = threadIdx.x & 63;
-  const int i = jstart + threadIdx.x;
-  const int iw0 = jstart + (threadIdx.x & ~63);  // first row of this wave
+  const int i = jstart + part * CONS_THREADS + threadIdx.x;
+  const int iw0 = jstart + part * CONS_THREADS + (threadIdx.x & ~63);  // first row of this wave
   const bool live = i < N;
   const bool wave_live = iw0 < N;
   const size_t mb = (size_t)pair * pb.mcap;
@@ -868,7 +883,7 @@ __global__ __launch_bounds__(256, CONS_MIN_WAVES) void k_consistency(PairBufs pb
     __syncthreads();
     // LDS layout: per pair of columns (2p, 2p+1) twelve floats  rx0 rx1 ry0 ry1 rz0 rz1 tx0 tx1 ty0 ty1 tz0 tz1,
     // so the packed-fp32 evaluation of two columns reads its operands with three 16-byte broadcasts
-    for (int k = threadIdx.x; k < nt * 3; k += 256) {
+    for (int k = threadIdx.x; k < nt * 3; k += CONS_THREADS) {
       const int c = k / 3, ax = k % 3;
       float* d = s_c + (c >> 1) * 12 + ax * 2 + (c & 1);
       d[0] = (float)pb.m_rxyz[(mb + j0) * 3 + k];
