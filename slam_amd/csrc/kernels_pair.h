@@ -346,7 +346,9 @@ __global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs 
 #define MATCH_THREADS 256
 #endif
 #define MATCH_WAVES (MATCH_THREADS / 64)
+#ifndef MATCH_QCAP
 #define MATCH_QCAP 256  // per-wave candidate queue entries; flushed when fewer than 64 slots are left
+#endif
 
 // SAD of two 80-byte descriptors (feature.hpp:364-381), both 16-byte aligned
 __device__ inline uint32_t sad80(const uint8_t* a, const uint8_t* b) {
