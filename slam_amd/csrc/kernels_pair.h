@@ -1257,7 +1257,7 @@ __device__ inline void inverse6(const double* A, double* inv) {
 // grid n_pairs, 256 threads.
 __global__ __launch_bounds__(256) void k_track_count(FrameBufs fb, FrameGeom g, PairBufs pb) {
   __shared__ int s_wave[8];
-  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x;
   if (!pb.active[pair]) {
     if (tid == 0) pb.new_tracks[pair] = 0;
     return;
@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(256) void k_track_count(FrameBufs fb, FrameGeom g, 
 __global__ __launch_bounds__(256) void k_track_assign(FrameBufs fb, FrameGeom g, PairBufs pb, int n_pairs, int mode,
                                                       int32_t* ctr_in, int32_t* ctr_out) {
   __shared__ int s_wave[8];
-  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x;  // (pair0 = 0 in mode 1)
   int base;
   if (mode == 1) {
     int before = 0, all = 0;
@@ -1368,14 +1368,15 @@ __global__ void k_stream_reset(StreamState* st, rvo_stream_result* out, int n, S
 }
 
 // vo.cpp:58-80: warm-up skip, buffer rotation; emits the slot/threshold the frame kernels use (-1 = skip)
-__global__ void k_stream_pre(StreamState* st, int n, StreamParams sp, int32_t* sslots /*[2n]: slot, thr*/, PairBufs pb) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
+// (all k_stream_* kernels: streams s0 .. s0+n-1; a stream's pair work area has the stream's index)
+__global__ void k_stream_pre(StreamState* st, int s0, int n, StreamParams sp, int32_t* sslots /*[2n]: slot, thr of the n streams*/, PairBufs pb) {
+  const int ls = blockIdx.x * blockDim.x + threadIdx.x, s = s0 + ls;
+  if (ls >= n) return;
   StreamState& S = st[s];
   S.processed = 0; S.estimate = 0; S.retry = 0;
   pb.active[s] = 0;
-  sslots[s] = -1;
-  sslots[n + s] = S.fast_thr;
+  sslots[ls] = -1;
+  sslots[n + ls] = S.fast_thr;
   if (S.init_cnt < sp.warmup) {
     ++S.init_cnt;
     if (S.init_cnt != sp.warmup) return;
@@ -1390,13 +1391,13 @@ __global__ void k_stream_pre(StreamState* st, int n, StreamParams sp, int32_t* s
   S.ref_changed = S.ref_changed_flag;
   S.ref_changed_flag = 0;
   iso_set_identity12(S.curr_to_prev);
-  sslots[s] = S.slot_curr;
+  sslots[ls] = S.slot_curr;
 }
 
 // vo.cpp:92-110: adaptive FAST threshold, first-frame handling, choice of the initial-rotation source
-__global__ void k_stream_mid(StreamState* st, int n, StreamParams sp, FrameBufs fb, FrameGeom g, PairBufs pb) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
+__global__ void k_stream_mid(StreamState* st, int s0, int n, StreamParams sp, FrameBufs fb, FrameGeom g, PairBufs pb) {
+  const int s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= s0 + n) return;
   StreamState& S = st[s];
   if (!S.processed) return;
   int det = 0;
@@ -1416,9 +1417,9 @@ __global__ void k_stream_mid(StreamState* st, int n, StreamParams sp, FrameBufs 
 }
 
 // vo.cpp:113-115: initial estimate = ref_to_prev^-1 rotated by the initial rotation
-__global__ void k_stream_init(StreamState* st, int n, PairBufs pb) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
+__global__ void k_stream_init(StreamState* st, int s0, int n, PairBufs pb) {
+  const int s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= s0 + n) return;
   StreamState& S = st[s];
   if (!S.estimate) return;
   DIso r2p;
@@ -1430,9 +1431,9 @@ __global__ void k_stream_init(StreamState* st, int n, PairBufs pb) {
 }
 
 // vo.cpp:124-143: accept the estimate vs the reference frame, or arm the retry vs the previous frame
-__global__ void k_stream_post1(StreamState* st, int n, PairBufs pb) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
+__global__ void k_stream_post1(StreamState* st, int s0, int n, PairBufs pb) {
+  const int s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= s0 + n) return;
   StreamState& S = st[s];
   if (!S.estimate) return;
   pb.active[s] = 0;
@@ -1468,9 +1469,9 @@ __device__ inline void traj_write(double* traj, int traj_cap, int s, const rvo_s
   t[12] = (double)o.status; t[13] = (double)o.num_inliers; t[14] = (double)o.rc; t[15] = (double)o.used_fallback;
 }
 
-__global__ void k_stream_post2(StreamState* st, int n, StreamParams sp, PairBufs pb, rvo_stream_result* out, double* traj, int traj_cap) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
+__global__ void k_stream_post2(StreamState* st, int s0, int n, StreamParams sp, PairBufs pb, rvo_stream_result* out, double* traj, int traj_cap) {
+  const int s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= s0 + n) return;
   StreamState& S = st[s];
   rvo_stream_result& o = out[s];
   o.used_fallback = 0;

@@ -99,6 +99,14 @@ struct rvo_ctx {
   // latency-bound tail of batch k runs beside the frame stages of batch k+1 and the pair stages of ... without ever
   // holding up the next submit.  Pair work areas exist kPairSets times (the R, P and T stages work on three different
   // batches at a time, one more set is slack); `pb` is the set of the latest batch.
+  // rvo_stream_step_dev: the streams of a step are cut into two groups that run as two chains (main stream, aux[0]);
+  // a group's FAST stage starts when the other group's is done, so the pair stages of one group run beside the frame
+  // stages of the other (what two contexts with rvo_wait_peer did in round 1)
+  bool stream_groups = true;     // env RVO_STREAM_GROUPS=0: one chain per step
+  int stream_group_min = 128;    // fewer streams than this run as one chain (env RVO_STREAM_GROUP_MIN; tests use 2)
+  hipEvent_t ev_gfast[2] = {nullptr, nullptr}, ev_gdone = nullptr;
+  bool ev_gfast_rec[2] = {false, false};
+  bool group_pending = false;    // group B of the latest step has not been joined into the main stream yet
   bool staged = true;            // env RVO_STAGED=0 / rvo_set_pipeline(ctx, 0): the chunked single-chain form
   static const int kPairSets = 4;
   int pair_sets = kPairSets;     // env RVO_PAIR_SETS (2..kPairSets): experiments
@@ -388,6 +396,10 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
   }
   for (int i = 0; i < rvo_ctx::kSlotRing; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_pdone[i], hipEventDisableTiming));
   if (const char* e = getenv("RVO_STAGED")) c->staged = atoi(e) != 0;
+  if (const char* e = getenv("RVO_STREAM_GROUPS")) c->stream_groups = atoi(e) != 0;
+  if (const char* e = getenv("RVO_STREAM_GROUP_MIN")) c->stream_group_min = std::max(2, atoi(e));
+  for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_gfast[i], hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_gdone, hipEventDisableTiming));
   c->slot_reader.assign((size_t)max_frames, -1);
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
@@ -482,6 +494,8 @@ void rvo_destroy(rvo_ctx* c) {
     for (auto e : evs) if (*e) (void)hipEventDestroy(*e);
   }
   for (int i = 0; i < rvo_ctx::kSlotRing; i++) if (c->ev_pdone[i]) (void)hipEventDestroy(c->ev_pdone[i]);
+  for (int i = 0; i < 2; i++) if (c->ev_gfast[i]) (void)hipEventDestroy(c->ev_gfast[i]);
+  if (c->ev_gdone) (void)hipEventDestroy(c->ev_gdone);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   for (int i = 0; i < 2; i++) {
@@ -494,7 +508,11 @@ void rvo_destroy(rvo_ctx* c) {
 
 // Orders the context's main stream after every staged batch still in flight (their pair and tail stages run on other
 // streams): called by every entry point that touches pair work areas or frame slots outside the staged pipeline.
-static int join_staged(rvo_ctx* c) {
+static int join_staged(rvo_ctx* c, bool keep_groups = false) {
+  if (c->group_pending && !keep_groups) {  // the second group of the latest stream step (rvo_stream_step_dev)
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_gdone, 0));
+    c->group_pending = false;
+  }
   for (int s = 0; s < rvo_ctx::kPairSets; s++) {
     if (!(c->staged_pending & (1 << s))) continue;
     if (c->ev_p_rec[s]) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_p[s], 0));
@@ -603,13 +621,16 @@ static int enqueue_pyramid_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* 
 static bool can_read_in_place(const rvo_ctx* c, const uint8_t* gray) {
   return c->g.levels >= 2 && c->g.lv[0].stride == c->g.W && ((uintptr_t)gray & 15) == 0;
 }
-static int enqueue_features_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots, const int32_t* d_thr) {
+static int enqueue_features_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots, const int32_t* d_thr,
+                               hipEvent_t wait_before_fast = nullptr, hipEvent_t record_after_fast = nullptr) {
   const FrameGeom& g = c->g;
+  if (wait_before_fast) HIPCHK(hipStreamWaitEvent(st, wait_before_fast, 0));
   if (c->fl.tile_pitch == 88 && c->fl.score_pitch == 84)  // the default 80x80 grid: pitches as compile-time constants
     LAUNCH_ON(c, st, "fast_grid", (k_fast_grid<88, 84>), dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
   else
     LAUNCH_ON(c, st, "fast_grid", (k_fast_grid<0, 0>), dim3(g.total_buckets, n), dim3(256), c->fl.total, c->fb, g, c->fl, d_slots, d_thr);
   if (st == c->stream) HIPCHK(hipEventRecord(c->ev_mid, st));  // rvo_wait_peer
+  if (record_after_fast) HIPCHK(hipEventRecord(record_after_fast, st));
   LAUNCH_ON(c, st, "build_keypoints", k_build_keypoints, dim3(g.levels, n), dim3(256), 0, c->fb, g, d_slots);
   HIPCHK(hipGetLastError());
   return RVO_OK;
@@ -655,6 +676,7 @@ int rvo_prepare_frames(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* d
   HIPCHK(hipSetDevice(c->device));
   const FrameGeom& g = c->g;
   { int rc0 = ensure_stage(c, n); if (rc0) return rc0; }
+  { const int rc0 = join_staged(c); if (rc0) return rc0; }  // the staging buffers may still be read by a stream step's second group
   HIPCHK(hipMemcpyAsync(c->d_gray_stage, gray, (size_t)n * g.W * g.H, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->d_depth_stage, depth, (size_t)n * g.Wd * g.Hd * 2, hipMemcpyHostToDevice, c->stream));
   int rc = rvo_prepare_frames_dev(c, n, c->d_gray_stage, c->d_depth_stage, thr, slots);

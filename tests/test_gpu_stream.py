@@ -11,9 +11,12 @@ from slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def test_streams_vs_oracle(scene, intr640):
+@pytest.mark.parametrize("grouped", [False, True])
+def test_streams_vs_oracle(scene, intr640, grouped, monkeypatch):
+    """grouped: the step runs as two interleaved chains (streams 0 | 1, 2), as it does from 128 streams on."""
     from oracle.pyoracle import Oracle, OracleVO, default_params as odef
     from slam_amd.api import RGBDVOStreams, default_params
+    monkeypatch.setenv("RVO_STREAM_GROUP_MIN", "2" if grouped else "1000000")
     n_streams, n_frames, warm = 3, 14, 3
     vo = RGBDVOStreams(intr640, n_streams, params=default_params(warmup_frames=warm))
     orcs = [Oracle(intr640, odef(warmup_frames=warm)) for _ in range(n_streams)]

@@ -32,7 +32,7 @@ if __name__ == "__main__":
     ctxs = [Context(intr, p, max_frames=3 * per, max_pairs=per) for _ in range(NC)]
     for c in ctxs:
         c.streams_reset(per)
-        c.set_pair_chunks(1)
+        c.set_pair_chunks(1 if NC > 1 else int(os.environ.get('RVO_PAIR_CHUNKS', '2')))
     torch.cuda.synchronize()
     order = list(range(T)) + list(range(T - 2, 0, -1))
     def step(k):
