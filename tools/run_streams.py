@@ -1,6 +1,6 @@
 """configs[2] end to end: S independent RGB-D streams sharded over the ranks of one node (one process per GPU,
-slam_amd.dist.shard_range), every rank advancing its streams in lock-step with rvo_stream_step_dev on two contexts, no
-collective in the loop; at the end ONE gather of the trajectories (RCCL, gloo fallback) and rank 0 writes them in
+slam_amd.dist.shard_range), every rank advancing its streams in lock-step with rvo_stream_step_dev on one context (the library
+interleaves two groups of streams itself; --contexts 2 adds round 1's two-context arrangement on top), no collective in the loop; at the end ONE gather of the trajectories (RCCL, gloo fallback) and rank 0 writes them in
 the pose graph's vertex file format (slam_amd/vertex_io.py) and prints one JSON line.
 
   python tools/run_streams.py --streams 64 --frames 12
@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--out", default="")
+    ap.add_argument("--contexts", type=int, default=1, choices=(1, 2), help="contexts per GPU (2: streams split over two contexts with rvo_wait_peer)")
     ap.add_argument("--gpus", type=int, default=1, help="started without torchrun: launch this many rank processes (one per GPU)")
     a = ap.parse_args()
     from slam_amd.launch import launched_by_parent, spawn_ranks
@@ -57,7 +58,7 @@ def main():
     torch.cuda.synchronize()
     p = default_params()
     p.warmup_frames = 1  # the reference discards 99 frames first (vo.cpp:58-69); the synthetic sequences start at once
-    halves = [range(0, S // 2), range(S // 2, S)] if S >= 2 else [range(0, S)]
+    halves = [range(0, S // 2), range(S // 2, S)] if (S >= 2 and a.contexts == 2) else [range(0, S)]
     ctxs = []
     for h in halves:
         c = Context(INTR, p, max_frames=3 * len(h), max_pairs=len(h), device=dev_index)
