@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     // Column strips: when 256 threads can take (group column, strip of <= 8 score rows) each, a thread reads the centre
     // dwords of the 14 tile rows its strip touches once, unpacks them once, and reuses every row as the "3 up", centre
     // and "3 down" row of three score rows (static register indexing, no index walkers).  The verdicts of a strip are
-    // shifted into two 32-bit masks (bright, dark): row k's pixels 0,1 at bits 2k+1, 2k and pixels 2,3 at 17+2k, 16+2k.
+    // shifted into two 32-bit masks (bright, dark): pixel p of row k at bit 8p + k.
     // Other shapes use the generic walker below (64-bit masks, 4 bits per visited group).
     const int seg = tid / ngr, sj = jlo + tid % ngr;
     int r0 = 0;  // first score row of this thread's strip (strips only)
@@ -495,12 +495,14 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
           uint32_t tbe, tde, tbo, tdo;
           compass2f(Ce[k + 3], Ce[k + 6], Ce[k], Ee, We, cd2, &tbe, &tde);
           compass2f(Co[k + 3], Co[k + 6], Co[k], Eo, Wo, cd2, &tbo, &tdo);
-          sb = (sb >> 2) | (tbe & 0x80008000u) | ((tbo >> 1) & 0x40004000u);
-          sdk = (sdk >> 2) | (tde & 0x80008000u) | ((tdo >> 1) & 0x40004000u);
+          // the verdicts are bit 15 of the halves = bit 7 of bytes 1 and 3: one v_perm gathers the four bytes (pixel p ->
+          // byte p), and shifting the mask right once per row leaves row k at bit k of every byte
+          sb = (sb >> 1) | (__builtin_amdgcn_perm(tbo, tbe, 0x07030501u) & 0x80808080u);
+          sdk = (sdk >> 1) | (__builtin_amdgcn_perm(tdo, tde, 0x07030501u) & 0x80808080u);
         }
-        const uint32_t keep = (((1u << (2 * nrows)) - 1u) * 0x00010001u) &
-                              (((vm & 1u) ? 0x0000AAAAu : 0u) | ((vm & 2u) ? 0x00005555u : 0u) | ((vm & 4u) ? 0xAAAA0000u : 0u) |
-                               ((vm & 8u) ? 0x55550000u : 0u));
+        const uint32_t keep = (((1u << nrows) - 1u) * 0x01010101u) &
+                              (((vm & 1u) ? 0x000000FFu : 0u) | ((vm & 2u) ? 0x0000FF00u : 0u) | ((vm & 4u) ? 0x00FF0000u : 0u) |
+                               ((vm & 8u) ? 0xFF000000u : 0u));
         sb &= keep; sdk &= keep;
       }
     }
@@ -548,12 +550,13 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     if (fits && strips) {
       // the loop runs as long as the fullest lane of the wave, so an entry is just (thread << 5 | mask bit); phase B,
       // where every lane has one entry, turns it into (sy << 8 | sx)
-      auto drain = [&](uint32_t m, int& pos, int step) {
+      auto drain = [&](uint32_t m, int pos, int step) {
+        uint16_t* q = s_cand + pos;
+        const uint32_t tag = (uint32_t)tid << 5;
         while (m) {
-          const int qb = __ffs(m) - 1;
+          *q = (uint16_t)(tag | (uint32_t)(__ffs(m) - 1));
           m &= m - 1;
-          s_cand[pos] = (uint16_t)((tid << 5) | qb);
-          pos += step;
+          q += step;
         }
       };
       drain(sb, posb, 1);
@@ -591,11 +594,11 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     const int qi = bright ? c : qcap - 1 - (c - nb);
     const int v = s_cand[qi];
     int sy = v >> 8, sx = v & 255;
-    if (strips) {  // entry = (producer thread << 5 | bit of its strip mask): row k's pixels 0,1 at bits 2k+1, 2k, pixels 2,3 at 17+2k, 16+2k
+    if (strips) {  // entry = (producer thread << 5 | bit of its strip mask): pixel p of row k at bit 8p + k
       const int t = v >> 5, qb = v & 31;
       const int seg = (t * inv_ngr) >> 16;
-      sy = max(seg * rows_per, sylo) + ((qb & 15) >> 1);
-      sx = 4 * (jlo + t - seg * ngr) + 1 - (qb & 1) + 2 * (qb >> 4) - 3 - shl;
+      sy = max(seg * rows_per, sylo) + (qb & 7);
+      sx = 4 * (jlo + t - seg * ngr) + (qb >> 3) - 3 - shl;
       s_cand[qi] = (uint16_t)((sy << 8) | sx);  // for the NMS pass (same thread, same entry)
     }
     const int A = fast9_A_pol(s_tile + (sy + 3) * TP + (sx + 3 + shl), TP, bright ? 1 : -1);
