@@ -341,6 +341,27 @@ __device__ int g_fast_stop;  // ablation: return after phase i (99 = run everyth
 #define FAST_PHASE(i) do { } while (0)
 #endif
 
+// ceil(65536 / n) for n = 1..256: x / n == (x * kInv16[n]) >> 16 whenever x < 512 and n <= 128 (the error of the
+// product is below x / 65536 < 1/128, which can only matter when x mod n == n - 1 and 1/n < 1/128).  The divisors in
+// k_fast_grid are wave-uniform but not compile-time constants; without the table each costs a dozen VALU instructions
+// of float reciprocal + fix-up.
+struct Inv16Table { uint32_t v[257]; };
+static constexpr Inv16Table make_inv16() {
+  Inv16Table t{};
+  t.v[0] = 0;
+  for (int n = 1; n <= 256; n++) t.v[n] = (65536u + n - 1) / n;
+  return t;
+}
+__constant__ Inv16Table kInv16 = make_inv16();
+// floor((2^32 - 1) / n) + 1: idx / n == umulhi(idx, kInv32[n]) for idx < 2^16, n < 2^8
+static constexpr Inv16Table make_inv32() {
+  Inv16Table t{};
+  t.v[0] = 0;
+  for (int n = 1; n <= 256; n++) t.v[n] = 0xFFFFFFFFu / (uint32_t)n + 1u;
+  return t;
+}
+__constant__ Inv16Table kInv32 = make_inv32();
+
 struct FastLds {  // byte offsets into dynamic LDS, computed on the host (all multiples of 4)
   int tile_pitch, score_pitch;
   int cand_cap;  // phase-A candidate queue entries (u16)
@@ -397,8 +418,9 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     // thread = (column word c, row r0s) with c fixed: the column's bounds and store guards are computed once, rows advance
     // by 256 / t16 per pass; three loads are in flight before their stores
     const int t16 = (shx + cw + 8 + 15) >> 4;  // 16-byte words per row (<= 18: cells are at most 253 wide)
-    const int rpp = 256 / t16;                 // rows per pass
-    const int r0s = (tid * ((65536 + t16 - 1) / t16)) >> 16, c = tid - r0s * t16;  // tid / t16, tid % t16 (exact for tid < 256)
+    const int inv_t16 = (int)kInv16.v[t16];
+    const int rpp = (256 * inv_t16) >> 16;     // rows per pass = 256 / t16
+    const int r0s = (tid * inv_t16) >> 16, c = tid - r0s * t16;  // tid / t16, tid % t16 (exact for tid <= 256)
     const int gx = gx0 + 16 * c;
     const int d0 = 4 * c - sd;
     const bool colok = gx >= 0 && gx < G.stride;
@@ -447,15 +469,16 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   const int qcap = L.cand_cap;
   // four-pixel groups: group j of score row sy covers tile x = 4j..4j+3 (score column sx sits at tile x = sx + 3 + shl)
   const int jlo = (shl + 3) >> 2, ngr = ((shl + sw + 2) >> 2) - jlo + 1;
-  const int nseg = 256 / ngr, rows_per = (sh + nseg - 1) / nseg;
+  const int inv_ngr = (int)kInv16.v[ngr];  // ngr <= 64; t / ngr == (t * inv_ngr) >> 16 for t <= 256
+  const int nseg = (256 * inv_ngr) >> 16, rows_per = ((sh + nseg - 1) * (int)kInv16.v[nseg]) >> 16;  // 256 / ngr, ceil(sh / nseg)
   const bool strips = rows_per <= 8;      // column strips (below); otherwise the generic walker
   const int sylo = max(0, 4 - cy0);       // first score row with gy >= 3
-  const int inv_ngr = (65536 + ngr - 1) / ngr;  // t / ngr == (t * inv_ngr) >> 16 for t < 256
   {
     // 4 horizontally adjacent pixels per iteration: aligned LDS dwords (centre, left, right, 3 rows up, 3 rows down)
     // feed two packed-u16 evaluations (even / odd bytes).  Group j of score row sy covers tile x = 4j..4j+3.
-    const int q = 256 / ngr, rr = 256 % ngr;
-    const int gsy0 = tid / ngr, gj0 = jlo + tid % ngr;
+    const int seg = (tid * inv_ngr) >> 16, sj = jlo + tid - seg * ngr;  // tid / ngr, jlo + tid % ngr
+    const int q = nseg, rr = 256 - nseg * ngr;
+    const int gsy0 = seg, gj0 = sj;
     const int txlo = max(3, 7 - cx0) + shl, txhi = min(sw + 2, G.w - cx0) + shl;  // fast9Detect loop bounds, feature.cpp:3042-3043
     const uint32_t cd1 = 0x7FFFu - (uint32_t)min(b, 255);
     const uint32_t cd2 = cd1 | (cd1 << 16);
@@ -464,7 +487,6 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     // and "3 down" row of three score rows (static register indexing, no index walkers).  The verdicts of a strip are
     // shifted into two 32-bit masks (bright, dark): pixel p of row k at bit 8p + k.
     // Other shapes use the generic walker below (64-bit masks, 4 bits per visited group).
-    const int seg = tid / ngr, sj = jlo + tid % ngr;
     int r0 = 0;  // first score row of this thread's strip (strips only)
     uint32_t sb = 0, sdk = 0;             // strips: bright / dark masks
     unsigned long long gb64 = 0, gd64 = 0;  // generic walker: bright / dark masks
@@ -643,7 +665,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   FAST_PHASE(3);  // NMS
   // ---- raster-ordered compaction of the bitmap (the order the reference pushes keypoints into the bucket)
   int total = 0, base_run = 0;
-  const uint32_t inv_cw = 0xFFFFFFFFu / (uint32_t)cw + 1u;  // idx / cw == umulhi(idx, inv_cw) for idx < 2^16, cw < 2^8
+  const uint32_t inv_cw = kInv32.v[cw];  // idx / cw == umulhi(idx, inv_cw) for idx < 2^16, cw < 2^8
   for (int w0 = 0; w0 < nwords; w0 += 256) {
     const int w = w0 + tid;
     uint32_t word = w < nwords ? s_bits[w] : 0u;
