@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
   const LevelGeom S = g.lv[lvl - 1], D = g.lv[lvl];
   int tile, fi;  // XCD-aware: the tiles of a frame share source lines
   xcd_map(gridDim.x * gridDim.y, gridDim.z, blockIdx.y * gridDim.x + blockIdx.x, blockIdx.z, &tile, &fi);
-  const int tile_y = tile / (int)gridDim.x, tile_x = tile - tile_y * (int)gridDim.x;
+  const int tile_y = (tile * (int)kInv16.v[gridDim.x]) >> 16, tile_x = tile - tile_y * (int)gridDim.x;  // tile / gridDim.x (tile < 512)
   const int slot = slots[fi];
   if (slot < 0) return;  // stream still in warm-up (vo.cpp:58-69)
   const uint8_t* __restrict__ src = gray_inplace ? gray_inplace + (size_t)fi * g.W * g.H : level_img(fb, g, slot, lvl - 1);
@@ -341,27 +341,6 @@ __device__ int g_fast_stop;  // ablation: return after phase i (99 = run everyth
 #define FAST_PHASE(i) do { } while (0)
 #endif
 
-// ceil(65536 / n) for n = 1..256: x / n == (x * kInv16[n]) >> 16 whenever x < 512 and n <= 128 (the error of the
-// product is below x / 65536 < 1/128, which can only matter when x mod n == n - 1 and 1/n < 1/128).  The divisors in
-// k_fast_grid are wave-uniform but not compile-time constants; without the table each costs a dozen VALU instructions
-// of float reciprocal + fix-up.
-struct Inv16Table { uint32_t v[257]; };
-static constexpr Inv16Table make_inv16() {
-  Inv16Table t{};
-  t.v[0] = 0;
-  for (int n = 1; n <= 256; n++) t.v[n] = (65536u + n - 1) / n;
-  return t;
-}
-__constant__ Inv16Table kInv16 = make_inv16();
-// floor((2^32 - 1) / n) + 1: idx / n == umulhi(idx, kInv32[n]) for idx < 2^16, n < 2^8
-static constexpr Inv16Table make_inv32() {
-  Inv16Table t{};
-  t.v[0] = 0;
-  for (int n = 1; n <= 256; n++) t.v[n] = 0xFFFFFFFFu / (uint32_t)n + 1u;
-  return t;
-}
-__constant__ Inv16Table kInv32 = make_inv32();
-
 struct FastLds {  // byte offsets into dynamic LDS, computed on the host (all multiples of 4)
   int tile_pitch, score_pitch;
   int cand_cap;  // phase-A candidate queue entries (u16)
@@ -402,7 +381,8 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     if (l < g.levels && gb >= g.lv[l].bucket_off) lvl = l;
   const LevelGeom G = g.lv[lvl];
   const int bi = gb - G.bucket_off;
-  const int cx0 = (bi % G.gcols) * g.gw, cy0 = (bi / G.gcols) * g.gh;
+  const int brow = (int)__umulhi((uint32_t)bi, kInv32.v[G.gcols]);  // bi / gcols (bi < 2^16, gcols <= 256)
+  const int cx0 = (bi - brow * G.gcols) * g.gw, cy0 = brow * g.gh;
   const int cw = min(g.gw, G.w - cx0), ch = min(g.gh, G.h - cy0);
   const uint8_t* __restrict__ img = level_img(fb, g, slot, lvl);
   const int TP = TPC ? TPC : L.tile_pitch, SP = SPC ? SPC : L.score_pitch;

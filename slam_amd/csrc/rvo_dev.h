@@ -107,14 +107,36 @@ extern "C" __device__ unsigned __llvm_amdgcn_writelane(unsigned val, unsigned la
 // L2s although they read the same images.  Within every group of 8 units the linear ids are re-dealt so that all items
 // of a unit are congruent mod 8 (same XCD); a tail of fewer than 8 units keeps the natural mapping.
 __device__ inline void xcd_map(int nx, int ny, int bx, int by, int* item, int* unit) {
-  const int lin = by * nx + bx, grp = lin / (8 * nx);
+  const int grp = by >> 3;  // = (by * nx + bx) / (8 * nx), without the division
   *item = bx; *unit = by;
   if (grp * 8 + 8 <= ny) {
-    const int r = lin - grp * 8 * nx;
+    const int r = (by & 7) * nx + bx;
     *unit = grp * 8 + (r & 7);
     *item = r >> 3;
   }
 }
+
+// ceil(65536 / n) for n = 1..256: x / n == (x * kInv16[n]) >> 16 whenever x * n < 65536 (the error of the product is
+// below x / 65536, which can only matter when x mod n == n - 1 and 1/n <= x / 65536).  The divisors in
+// k_fast_grid are wave-uniform but not compile-time constants; without the table each costs a dozen VALU instructions
+// of float reciprocal + fix-up.
+struct Inv16Table { uint32_t v[257]; };
+static constexpr Inv16Table make_inv16() {
+  Inv16Table t{};
+  t.v[0] = 0;
+  for (int n = 1; n <= 256; n++) t.v[n] = (65536u + n - 1) / n;
+  return t;
+}
+__constant__ Inv16Table kInv16 = make_inv16();
+// floor((2^32 - 1) / n) + 1: idx / n == umulhi(idx, kInv32[n]) for idx < 2^16, n <= 2^8
+static constexpr Inv16Table make_inv32() {
+  Inv16Table t{};
+  t.v[0] = 0;
+  for (int n = 1; n <= 256; n++) t.v[n] = 0xFFFFFFFFu / (uint32_t)n + 1u;
+  return t;
+}
+__constant__ Inv16Table kInv32 = make_inv32();
+
 
 __device__ inline const uint8_t* level_img(const FrameBufs& fb, const FrameGeom& g, int slot, int lvl) {
   return lvl == 0 ? fb.l0_tab[slot] : fb.img + (size_t)slot * g.img_bytes + g.lv[lvl].img_off;
