@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
     float ru = 0.f, rv = 0.f;
     double X = 0, Y = 0, Z = 0;
     if (s < nslots) {
-      const int bk = s / g.max_per, j = s % g.max_per;
+      const int bk = div_u16(s, g.max_per), j = s - bk * g.max_per;
       if (j < bk_cnt[bk]) {
         k = bk_kp[s];
         const int x = kp_x(k), y = kp_y(k);

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs 
   const int f = 1 << ds;
   const double pf2 = (double)f * (double)f;
   for (int i = tid; i < npx; i += 256) {
-    const int ey = i / cols, ex = i % cols;
+    const int ey = div_u16(i, cols), ex = i - ey * cols;
     float a = 0.f, b = 0.f;
     for (int y = 0; y < f; y++)
       for (int x = 0; x < f; x++) {
@@ -245,7 +245,10 @@ __global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs 
     else if (y == rows - 1) vy = im[y * cols + x] - im[(y - 1) * cols + x];
     else vy = (float)((double)(im[(y + 1) * cols + x] - im[(y - 1) * cols + x]) / 2.0);
   };
-  for (int i = tid; i < npx; i += 256) grad(tmpl, i % cols, i / cols, tdx[i], tdy[i]);
+  for (int i = tid; i < npx; i += 256) {
+    const int y = div_u16(i, cols);
+    grad(tmpl, i - y * cols, y, tdx[i], tdy[i]);
+  }
 
   float H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, bestH[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   double minError = INFINITY, lastRMS = INFINITY;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs 
     __syncthreads();
     // constructWarpedImage, :1538-1571
     for (int i = tid; i < npx; i += 256) {
-      const int y = i / cols, x = i % cols;
+      const int y = div_u16(i, cols), x = i - y * cols;
       const float hx = (H[0] * (float)x + H[1] * (float)y) + H[2] * 1.f;
       const float hy = (H[3] * (float)x + H[4] * (float)y) + H[5] * 1.f;
       const float hw = (H[6] * (float)x + H[7] * (float)y) + H[8] * 1.f;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs 
 #pragma unroll
     for (int k = 0; k < 10; k++) acc[k] = 0;
     for (int i = tid; i < npx; i += 256) {
-      const int y = i / cols, x = i % cols;
+      const int y = div_u16(i, cols), x = i - y * cols;
       const float e = warped[i] - tmpl[i];
       float wx, wy;
       grad(warped, x, y, wx, wy);

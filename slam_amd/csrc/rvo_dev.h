@@ -136,6 +136,8 @@ static constexpr Inv16Table make_inv32() {
   return t;
 }
 __constant__ Inv16Table kInv32 = make_inv32();
+// x / n for a divisor that is uniform but only known at run time (x < 2^16)
+__device__ inline int div_u16(int x, int n) { return n <= 256 ? (int)__umulhi((uint32_t)x, kInv32.v[n]) : x / n; }
 
 
 __device__ inline const uint8_t* level_img(const FrameBufs& fb, const FrameGeom& g, int slot, int lvl) {
