@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
     const int r = i / (PYR_SCOLS / 16), c16 = i % (PYR_SCOLS / 16);
     const int gy = sy0 + r, gx = sx0 + 16 * c16;  // multiple of 16; level strides are multiples of 16
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (gy >= 0 && gy < S.h && gx >= 0 && gx < S.stride) v = *reinterpret_cast<const uint4*>(src + (size_t)gy * S.stride + gx);
+    if (gy >= 0 && gy < S.h && gx >= 0 && gx < S.stride) v = gload_u4(src + (size_t)gy * S.stride + gx);
     *reinterpret_cast<uint4*>(&s_src[r][16 * c16]) = v;
   }
   __syncthreads();
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
         for (int u = 0; u < 3; u++) {
           const int gy = gy0 + r + u * rpp;
           v[u] = make_uint4(0u, 0u, 0u, 0u);
-          if (colok && r + u * rpp < trows && gy >= 0 && gy < G.h) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)gy * G.stride);
+          if (colok && r + u * rpp < trows && gy >= 0 && gy < G.h) v[u] = gload_u4(src + (size_t)gy * G.stride);
         }
 #pragma unroll
         for (int u = 0; u < 3; u++) {

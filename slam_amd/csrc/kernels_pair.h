@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs 
     float a = 0.f, b = 0.f;
     for (int y = 0; y < f; y++)
       for (int x = 0; x < f; x++) {
-        a += (float)rimg[(size_t)(ey * f + y) * G.stride + ex * f + x];
-        b += (float)timg[(size_t)(ey * f + y) * G.stride + ex * f + x];
+        a += (float)gload<uint8_t>(rimg + (size_t)(ey * f + y) * G.stride + ex * f + x);
+        b += (float)gload<uint8_t>(timg + (size_t)(ey * f + y) * G.stride + ex * f + x);
       }
     tmpl[i] = ds > 0 ? (float)((double)a / pf2) : a;
     test[i] = ds > 0 ? (float)((double)b / pf2) : b;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(REFINE_THREADS, REFINE_MIN_WAVES) void k_refine(Fra
 #pragma unroll
       for (int q = 0; q < REFINE_WIN_PITCH / 4; q++) {
         const int x = xa + 4 * q;
-        dw[q] = (y >= 0 && y < G.h && x >= 0 && x + 3 < S) ? *reinterpret_cast<const uint32_t*>(tg + y * S + x) : 0u;
+        dw[q] = (y >= 0 && y < G.h && x >= 0 && x + 3 < S) ? gload<uint32_t>(tg + y * S + x) : 0u;
       }
 #pragma unroll
       for (int q = 0; q < REFINE_WIN_PITCH / 4; q++) reinterpret_cast<uint32_t*>(win + wr * REFINE_WIN_PITCH)[q] = dw[q];
@@ -667,9 +667,9 @@ __global__ __launch_bounds__(REFINE_THREADS, REFINE_MIN_WAVES) void k_refine(Fra
 #pragma unroll
   for (int m = 0; m < REFINE_TAPS; m++) {
     const int kr = rbase + toff[m];
-    rraw[m] = rg[kr];
-    rdx[m] = rg[kr + 1] - rraw[m];
-    rdy[m] = rg[kr + S] - rraw[m];
+    rraw[m] = gload<uint8_t>(rg + kr);
+    rdx[m] = gload<uint8_t>(rg + kr + 1) - rraw[m];
+    rdy[m] = gload<uint8_t>(rg + kr + S) - rraw[m];
     traw[m] = interp(wt, m, tnb[m]);
     rsum += rraw[m];
     tsum += traw[m];

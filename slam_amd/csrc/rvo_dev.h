@@ -140,6 +140,18 @@ __constant__ Inv16Table kInv32 = make_inv32();
 __device__ inline int div_u16(int x, int n) { return n <= 256 ? (int)__umulhi((uint32_t)x, kInv32.v[n]) : x / n; }
 
 
+// A pointer that was loaded from memory (the per-slot image / depth tables) is "generic" to the compiler, and accesses
+// through it become FLAT instructions, which also occupy the LDS queue and its wait counter.  Everything these tables
+// name is device global memory: gload reads through an address-space-1 pointer, i.e. with a GLOBAL load.
+template <class T>
+__device__ inline T gload(const void* p) {  // scalar types
+  return *(const __attribute__((address_space(1))) T*)p;
+}
+__device__ inline uint4 gload_u4(const void* p) {  // 16 bytes, 16-byte aligned
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t v = *(const __attribute__((address_space(1))) u32x4_t*)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ inline const uint8_t* level_img(const FrameBufs& fb, const FrameGeom& g, int slot, int lvl) {
   return lvl == 0 ? fb.l0_tab[slot] : fb.img + (size_t)slot * g.img_bytes + g.lv[lvl].img_off;
 }
