@@ -2,6 +2,7 @@
 import os
 import sys
 
+import pytest
 import numpy as np
 import torch.multiprocessing as mp
 
@@ -72,3 +73,35 @@ def test_vertex_file_format_roundtrip(tmp_path):
     got_ids, got = vertex_io.load_vertices(p)
     assert got_ids.tolist() == ids and np.array_equal(got[:, :3], poses)
     assert np.array_equal(vertex_io.load_vertex_by_id(p, 9)[:3], poses[4]) and vertex_io.load_vertex_by_id(p, 5) is None
+
+
+def test_vertex_file_cpp_and_python_agree(tmp_path):
+    """include/rgbdvo/vertex_io.hpp (the C++ caller's side of pose_graph.cpp:147-199) writes what slam_amd/vertex_io.py
+    reads, byte for byte, and reads what it writes."""
+    import subprocess
+    import numpy as np
+    from slam_amd import vertex_io
+    exe = str(tmp_path / "test_vertex_io")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "test_vertex_io.cpp")])
+    n = 6
+    want = np.empty((n, 3, 4))
+    for i in range(n):
+        for k in range(12):
+            want[i].flat[k] = (i + 1) * 0.125 + k * 1.0 / 3.0 - (7.0 / (i + 2) if k % 4 == 3 else 0.0)
+    ids = [3 * i + 1 for i in range(n)]
+    p_cpp, p_py = str(tmp_path / "cpp.bin"), str(tmp_path / "py.bin")
+    subprocess.check_call([exe, "write", p_cpp, str(n)])
+    got_ids, got = vertex_io.load_vertices(p_cpp)
+    assert got_ids.tolist() == ids and np.array_equal(got[:, :3], want) and np.array_equal(got[:, 3], np.tile([0, 0, 0, 1.0], (n, 1)))
+    vertex_io.save_vertices(p_py, ids, want)
+    assert open(p_py, "rb").read() == open(p_cpp, "rb").read()
+    lines = subprocess.check_output([exe, "read", p_py], text=True).strip().splitlines()
+    assert lines[-1] == "by_id 1 0"
+    back = np.array([[float(x) for x in ln.split()[1:]] for ln in lines[:-1]]).reshape(n, 3, 4)
+    assert [int(ln.split()[0]) for ln in lines[:-1]] == ids and np.array_equal(back, want)
+    # a truncated file is refused by both sides
+    open(p_py, "ab").write(b"\0" * 10)
+    assert subprocess.call([exe, "read", p_py]) == 1
+    with pytest.raises(ValueError):
+        vertex_io.load_vertices(p_py)
