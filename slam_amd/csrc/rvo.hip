@@ -99,14 +99,15 @@ struct rvo_ctx {
   // latency-bound tail of batch k runs beside the frame stages of batch k+1 and the pair stages of ... without ever
   // holding up the next submit.  Pair work areas exist kPairSets times (the R, P and T stages work on three different
   // batches at a time, one more set is slack); `pb` is the set of the latest batch.
-  // rvo_stream_step_dev: the streams of a step are cut into two groups that run as two chains (main stream, aux[0]);
+  // rvo_stream_step_dev: the streams of a step are cut into groups that run as chains of their own (main stream, aux[]);
   // a group's FAST stage starts when the other group's is done, so the pair stages of one group run beside the frame
   // stages of the other (what two contexts with rvo_wait_peer did in round 1)
-  bool stream_groups = true;     // env RVO_STREAM_GROUPS=0: one chain per step
+  int stream_groups = 4;         // groups of streams a step is cut into, each a chain on a stream of its own (env RVO_STREAM_GROUPS = 1..kMaxGroups; 0 and 1: one chain per step)
+  static constexpr int kMaxGroups = 4;
   int stream_group_min = 128;    // fewer streams than this run as one chain (env RVO_STREAM_GROUP_MIN; tests use 2)
-  hipEvent_t ev_gfast[2] = {nullptr, nullptr}, ev_gdone = nullptr;
-  bool ev_gfast_rec[2] = {false, false};
-  bool group_pending = false;    // group B of the latest step has not been joined into the main stream yet
+  hipEvent_t ev_gfast[kMaxGroups] = {}, ev_gdone[kMaxGroups - 1] = {};
+  bool ev_gfast_rec[kMaxGroups] = {};
+  int group_pending = 0;         // groups of the latest step (beyond the first) not yet joined into the main stream
   bool staged = true;            // env RVO_STAGED=0 / rvo_set_pipeline(ctx, 0): the chunked single-chain form
   static const int kPairSets = 4;
   int pair_sets = kPairSets;     // env RVO_PAIR_SETS (2..kPairSets): experiments
@@ -396,10 +397,10 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
   }
   for (int i = 0; i < rvo_ctx::kSlotRing; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_pdone[i], hipEventDisableTiming));
   if (const char* e = getenv("RVO_STAGED")) c->staged = atoi(e) != 0;
-  if (const char* e = getenv("RVO_STREAM_GROUPS")) c->stream_groups = atoi(e) != 0;
+  if (const char* e = getenv("RVO_STREAM_GROUPS")) c->stream_groups = std::min(std::max(atoi(e), 1), (int)rvo_ctx::kMaxGroups);
   if (const char* e = getenv("RVO_STREAM_GROUP_MIN")) c->stream_group_min = std::max(2, atoi(e));
-  for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_gfast[i], hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_gdone, hipEventDisableTiming));
+  for (int i = 0; i < rvo_ctx::kMaxGroups; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_gfast[i], hipEventDisableTiming));
+  for (int i = 0; i < rvo_ctx::kMaxGroups - 1; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_gdone[i], hipEventDisableTiming));
   c->slot_reader.assign((size_t)max_frames, -1);
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
@@ -494,8 +495,8 @@ void rvo_destroy(rvo_ctx* c) {
     for (auto e : evs) if (*e) (void)hipEventDestroy(*e);
   }
   for (int i = 0; i < rvo_ctx::kSlotRing; i++) if (c->ev_pdone[i]) (void)hipEventDestroy(c->ev_pdone[i]);
-  for (int i = 0; i < 2; i++) if (c->ev_gfast[i]) (void)hipEventDestroy(c->ev_gfast[i]);
-  if (c->ev_gdone) (void)hipEventDestroy(c->ev_gdone);
+  for (int i = 0; i < rvo_ctx::kMaxGroups; i++) if (c->ev_gfast[i]) (void)hipEventDestroy(c->ev_gfast[i]);
+  for (int i = 0; i < rvo_ctx::kMaxGroups - 1; i++) if (c->ev_gdone[i]) (void)hipEventDestroy(c->ev_gdone[i]);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
   for (int i = 0; i < 2; i++) {
@@ -509,9 +510,9 @@ void rvo_destroy(rvo_ctx* c) {
 // Orders the context's main stream after every staged batch still in flight (their pair and tail stages run on other
 // streams): called by every entry point that touches pair work areas or frame slots outside the staged pipeline.
 static int join_staged(rvo_ctx* c, bool keep_groups = false) {
-  if (c->group_pending && !keep_groups) {  // the second group of the latest stream step (rvo_stream_step_dev)
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_gdone, 0));
-    c->group_pending = false;
+  if (c->group_pending && !keep_groups) {  // the other groups of the latest stream step (rvo_stream_step_dev)
+    for (int i = 0; i < c->group_pending; i++) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_gdone[i], 0));
+    c->group_pending = 0;
   }
   for (int s = 0; s < rvo_ctx::kPairSets; s++) {
     if (!(c->staged_pending & (1 << s))) continue;

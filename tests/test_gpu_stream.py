@@ -11,13 +11,15 @@ from slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("grouped", [False, True])
-def test_streams_vs_oracle(scene, intr640, grouped, monkeypatch):
-    """grouped: the step runs as two interleaved chains (streams 0 | 1, 2), as it does from 128 streams on."""
+@pytest.mark.parametrize("groups", [1, 2, 4])
+def test_streams_vs_oracle(scene, intr640, groups, monkeypatch):
+    """groups > 1: the step runs as that many interleaved chains on streams of their own (2: streams 0 | 1, 2; 4: 0 | 1 | 2 |
+    3, 4), as it does from 128 streams on."""
     from oracle.pyoracle import Oracle, OracleVO, default_params as odef
     from slam_amd.api import RGBDVOStreams, default_params
-    monkeypatch.setenv("RVO_STREAM_GROUP_MIN", "2" if grouped else "1000000")
-    n_streams, n_frames, warm = 3, 14, 3
+    monkeypatch.setenv("RVO_STREAM_GROUP_MIN", "2")
+    monkeypatch.setenv("RVO_STREAM_GROUPS", str(groups))
+    n_streams, n_frames, warm = (5 if groups == 4 else 3), 14, 3
     vo = RGBDVOStreams(intr640, n_streams, params=default_params(warmup_frames=warm))
     orcs = [Oracle(intr640, odef(warmup_frames=warm)) for _ in range(n_streams)]
     ovos = [OracleVO(o) for o in orcs]
