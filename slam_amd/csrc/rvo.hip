@@ -208,8 +208,8 @@ static int scratch_for_device(int device) {
   return RVO_OK;
 }
 
-#ifdef RVO_SKIP_EXPERIMENT  // one-off builds: RVO_SKIP=<kernel name> drops that launch (what does it cost the pipeline?)
-#define RVO_SKIPPED(NAME) (getenv("RVO_SKIP") && strcmp(getenv("RVO_SKIP"), NAME) == 0)
+#ifdef RVO_SKIP_EXPERIMENT  // one-off builds: RVO_SKIP=<kernel names> drops those launches, results go stale (what do they cost the pipeline?)
+#define RVO_SKIPPED(NAME) ((c)->batch_id > 12 && getenv("RVO_SKIP") && strstr(getenv("RVO_SKIP"), NAME) != nullptr)  // after every slot set has been filled once
 #else
 #define RVO_SKIPPED(NAME) false
 #endif
