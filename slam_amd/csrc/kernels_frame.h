@@ -611,9 +611,10 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
       const int sy = i / sw, sx = i - sy * sw;
       const int gx = cx0 + sx - 1, gy = cy0 + sy - 1;
       if (gx < 3 || gx > G.w - 4 || gy < 3 || gy > G.h - 4) continue;  // fast9Detect loop bounds, feature.cpp:3042-3043
-      int d[16];
-      fast9_ring_diffs(s_tile + (sy + 3) * TP + (sx + 3 + shl), TP, d);
-      const int A = fast9_A(d);
+      // both polarities through the packed evaluation of phase B (fast9_A's sixteen-register form would set the
+      // kernel's register count): A = the larger one, as in fast9_A
+      const uint8_t* t = s_tile + (sy + 3) * TP + (sx + 3 + shl);
+      const int A = max(fast9_A_pol(t, TP, 1), fast9_A_pol(t, TP, -1));
       if (A > b) s_score[sy * SP + sx] = (uint8_t)A;
     }
   }
@@ -677,6 +678,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   const int keep = min(n, maxp);
   const size_t bslot = ((size_t)slot * g.total_buckets + gb) * maxp;
   uint32_t* out = fb.bk_kp + bslot;
+#pragma unroll 1
   for (int i = tid; i < keep; i += 256) out[i] = s_list[i];
   if (tid == 0) {
     fb.bk_cnt[(size_t)slot * g.total_buckets + gb] = keep;
