@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
           const uint32_t R = *reinterpret_cast<const uint32_t*>(row + 4);
           // west = tile x-3 of the four pixels = Lw.b1 Lw.b2 Lw.b3 C.b0; east = x+3 = C.b3 R.b0 R.b1 R.b2
           const uint32_t We = __builtin_amdgcn_perm(0u, Lw, 0x0C030C01u), Wo = __builtin_amdgcn_perm(C, Lw, 0x0C040C02u);
-          const uint32_t Ee = __builtin_amdgcn_perm(R, C, 0x0C050C03u), Eo = __builtin_amdgcn_perm(R, 0u, 0x0C060C04u);
+          const uint32_t Ee = __builtin_amdgcn_perm(R, C, 0x0C050C03u), Eo = R & 0x00FF00FFu;
           uint32_t tbe, tde, tbo, tdo;
           compass2f(Ce[k + 3], Ce[k + 6], Ce[k], Ee, We, cd2, &tbe, &tde);
           compass2f(Co[k + 3], Co[k + 6], Co[k], Eo, Wo, cd2, &tbo, &tdo);
