@@ -1,8 +1,9 @@
 // kernels_gn.h -- k_gn: MotionEstimator::refineMotionEstimate() twice with the reprojection pruning in between and the
 // final status (rgbdvo/motion_estimate.cpp:198-232, 610-720, 1208-1331).  Included by kernels_pair.h.
 //
-// One workgroup of 256 threads (one wave per SIMD) per pair; <= 128 VGPRs and < 8 KB of LDS, so the VALU-bound kernels
-// of the other batch in flight keep most of every CU while this latency-bound kernel runs beside them.
+// One workgroup of 256 threads (one wave per SIMD) per pair; 168 VGPRs and 7.3 KB of LDS with the inlier list: what seven
+// k_fast_grid workgroups (48 VGPRs, 22 KB each) leave free on a CU, so a workgroup of this latency-bound kernel is placed
+// without waiting for FAST workgroups to retire.
 //
 // refineMotionEstimateBidirectional (:1208-1331) evaluates, per iteration, the Jacobian at the current parameters and
 // then the error at the trial estimate.  The error at an ACCEPTED trial estimate is the error vector of the next
@@ -30,7 +31,7 @@ struct GnShared {
   double T[6][12];     // elimination tableau of the 6x6 inverse
   double H[GN_NACC];   // sums of the last pass
   double Hacc[GN_NACC];  // sums at the accepted estimate
-  double part[GN_WAVES * 4][32];  // per wave and row of 16 lanes: the row's sums of the 28 (padded to 32) values
+  double part[GN_WAVES][32];  // per wave: its sums of the 28 (padded to 32) values
   double est[6], next[6], delta[6], motion[12], nmotion[12];
   double sc[6], sch[6];  // sin/cos of the trial roll, pitch, yaw and of their halves
   double final_sse, mean;
@@ -369,8 +370,14 @@ __global__ __launch_bounds__(GN_THREADS, GN_MIN_WAVES) void k_gn(PairBufs pb, Ca
         }
         GN_T(7);  // pass over the inliers
         gn_row_reduce_scatter32(acc, lane);
-        {
-          double* o = &S.part[wid * 4 + (lane >> 4)][2 * (lane & 15)];
+        // the four rows of the wave, lane by lane: (row 0 + row 1) + (row 2 + row 3), then the waves in order
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          acc[q] += __shfl_xor(acc[q], 16, 64);
+          acc[q] += __shfl_xor(acc[q], 32, 64);
+        }
+        if (lane < 16) {
+          double* o = &S.part[wid][2 * lane];
           o[0] = acc[0];
           o[1] = acc[1];
         }
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(GN_THREADS, GN_MIN_WAVES) void k_gn(PairBufs pb, Ca
         if (tid < GN_NACC) {
           double s = S.part[0][tid];
 #pragma unroll
-          for (int r = 1; r < GN_WAVES * 4; r++) s += S.part[r][tid];
+          for (int r = 1; r < GN_WAVES; r++) s += S.part[r][tid];
           S.H[tid] = s;
         }
         __syncthreads();
