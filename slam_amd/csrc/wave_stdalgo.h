@@ -121,7 +121,12 @@ __device__ inline void wave_nth_element(uint32_t* a, int nth, int n, uint16_t* l
 // 2*lg(n)) and continues with the left part.  The order in which ranges are processed does not change the result.
 // Scratch: li, ri, leaf_s, leaf_e (u16[n] each; the partition of [first,last) only uses li/ri[first..last)), tmp
 // (u32[n]), ctl (int[4 + SORT_QCAP*2 + NW*SORT_STACK*2]).
-#define SORT_QCAP 1024
+// Queue entries are used once (no wrap-around): a sort of n keys publishes at most n / 17 ranges, so 128 entries cover
+// n <= 2176 (the default configuration's 1600 matches) without ever using the private stacks; beyond that a wave keeps
+// the ranges the queue has no room for on its own stack and works through them itself (same result, less parallel).
+#ifndef SORT_QCAP
+#define SORT_QCAP 128
+#endif
 #define SORT_STACK 32
 __device__ inline int sort_ctl_ints(int nwaves) { return 4 + SORT_QCAP * 2 + nwaves * SORT_STACK * 2; }
 
