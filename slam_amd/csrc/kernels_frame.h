@@ -47,6 +47,29 @@ __device__ inline int block_excl_scan_256(int v, int* s_wave, int* total) {
   return base + inc - v;
 }
 
+// 64-bit variant (several small counters packed into one word): Hillis-Steele over the wave with shuffles
+__device__ inline unsigned long long block_excl_scan_256_u64(unsigned long long v, unsigned long long* s_wave, unsigned long long* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) s_wave[wid] = inc;
+  __syncthreads();
+  unsigned long long base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const unsigned long long t = s_wave[w];
+    if (w < wid) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
 // same for any block size of NW waves (s_wave: NW ints)
 template <int NW>
 __device__ inline int block_excl_scan(int v, int* s_wave, int* total) {
@@ -725,9 +748,11 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
 
 // ------------------------------------------------------------------ keypoint records + XYZ
 // grid (levels, n_frames), 256 threads.
+#define BK_CP 4  // descriptor-copy trips in flight (8: slower)
+#define BK_CH 3  // 256-slot chunks examined together (5, the whole default level 0 in one go: 0.081 ms alone against 0.054)
 __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots) {
   RVO_OCC_SCOPE(3, 1);
-  __shared__ int s_wave[4];
+  __shared__ unsigned long long s_wave64[4];
   __shared__ int s_red[8];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lvl = blockIdx.x;
@@ -752,68 +777,109 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
     fb.grid_cnt[slot * RVO_MAX_LEVELS + lvl] = s_red[4] + s_red[5] + s_red[6] + s_red[7];
   }
 
-  // frame.cpp:92-142
+  // frame.cpp:92-142.  BK_CH chunks of 256 bucket slots are examined together: their gathers (bucket count -> keypoint ->
+  // undistortion LUT -> depth) are all in flight at once, one block scan (the
+  // chunks' flags packed 10 bits apiece) places them.
   const int mde = (RVO_WIN - 1) / 2 + 1;
   const int min_x = mde, min_y = mde, max_x = G.w - (mde + 1), max_y = G.h - (mde + 1);
   const int nslots = G.nbuckets * g.max_per;
   int base = 0;
-  for (int c0 = 0; c0 < nslots; c0 += 256) {
-    const int s = c0 + tid;
-    int flag = 0;
-    uint32_t k = 0;
-    float ru = 0.f, rv = 0.f;
-    double X = 0, Y = 0, Z = 0;
-    if (s < nslots) {
-      const int bk = div_u16(s, g.max_per), j = s - bk * g.max_per;
-      if (j < bk_cnt[bk]) {
-        k = bk_kp[s];
-        const int x = kp_x(k), y = kp_y(k);
-        if (!(x < min_x || x > max_x || y < min_y || y > max_y)) {
-          const int idx = (y << lvl) * g.W + (x << lvl);
-          ru = fb.xmap[idx];
-          rv = fb.ymap[idx];
-          if (!(ru < 0 || ru >= (float)g.W || rv < 0 || rv >= (float)g.H)) {
-            const int du = (int)((double)ru + 0.5), dv = (int)((double)rv + 0.5);
-            // Depth::RGB2DepthIdx, depth.hpp:41-43
-            const int di = (int)((double)dv * (double)g.ys) * g.Wd + (int)((double)du * (double)g.xs);
-            // rect_u in [W-0.5, W) rounds to du = W (distorted cameras only): the reference then reads the depth pixel
-            // and the ray (rays_->col(v*W+u), depth.cpp:72) of column 0 of the NEXT row; past the last row both reads
-            // leave their buffers (undefined there: Eigen's assert aborts) -- such a keypoint is dropped here.
-            const int ri = dv * g.W + du;
-            const uint16_t d = (di < g.Wd * g.Hd && ri < g.W * g.H) ? depth[di] : (uint16_t)0;
-            if (d) {  // HaveXYZ: d ? d*1e-3 : NaN
-              flag = 1;
-              const double z = (double)(float)((double)d * 1e-3);
-              const int rxu = du < g.W ? du : du - g.W, ryv = du < g.W ? dv : dv + 1;  // pixel the ray index ri names
-              const double rx = (double)rxu * g.fx_inv + g.neg_cx_div_fx;
-              const double ry = (double)ryv * g.fy_inv + g.neg_cy_div_fy;
-              X = z * rx; Y = z * ry; Z = z;
-            }
-          }
-        }
+  const int npx_rgb = g.W * g.H, npx_d = g.Wd * g.Hd;
+  for (int c0 = 0; c0 < nslots; c0 += 256 * BK_CH) {
+    // Every gather below is issued for every lane with a clamped (always valid) index and its result is masked
+    // afterwards: loads under divergent conditions would each wait for their data before the next chunk's is issued.
+    int flag[BK_CH];
+    uint32_t k[BK_CH];
+    float ru[BK_CH], rv[BK_CH];
+    double X[BK_CH], Y[BK_CH], Z[BK_CH];
+    bool have[BK_CH];
+    int cnt[BK_CH], jj[BK_CH];
+#pragma unroll
+    for (int u = 0; u < BK_CH; u++) {
+      const int s = min(c0 + u * 256 + tid, nslots - 1);
+      const int bk = div_u16(s, g.max_per);
+      jj[u] = s - bk * g.max_per;
+      cnt[u] = bk_cnt[bk];
+      k[u] = bk_kp[s];
+    }
+    int idx[BK_CH];
+#pragma unroll
+    for (int u = 0; u < BK_CH; u++) {
+      have[u] = (c0 + u * 256 + tid < nslots) && jj[u] < cnt[u];
+      const int x = kp_x(k[u]), y = kp_y(k[u]);
+      have[u] = have[u] && !(x < min_x || x > max_x || y < min_y || y > max_y);
+      idx[u] = have[u] ? (y << lvl) * g.W + (x << lvl) : 0;  // a slot beyond its bucket's count holds stale bits
+    }
+#pragma unroll
+    for (int u = 0; u < BK_CH; u++) {
+      ru[u] = fb.xmap[idx[u]];
+      rv[u] = fb.ymap[idx[u]];
+    }
+    int du[BK_CH], dv[BK_CH];
+    uint16_t dd[BK_CH];
+#pragma unroll
+    for (int u = 0; u < BK_CH; u++) {
+      have[u] = have[u] && !(ru[u] < 0 || ru[u] >= (float)g.W || rv[u] < 0 || rv[u] >= (float)g.H);
+      du[u] = (int)((double)ru[u] + 0.5); dv[u] = (int)((double)rv[u] + 0.5);
+      // Depth::RGB2DepthIdx, depth.hpp:41-43
+      const int di = (int)((double)dv[u] * (double)g.ys) * g.Wd + (int)((double)du[u] * (double)g.xs);
+      // rect_u in [W-0.5, W) rounds to du = W (distorted cameras only): the reference then reads the depth pixel
+      // and the ray (rays_->col(v*W+u), depth.cpp:72) of column 0 of the NEXT row; past the last row both reads
+      // leave their buffers (undefined there: Eigen's assert aborts) -- such a keypoint is dropped here.
+      const int ri = dv[u] * g.W + du[u];
+      have[u] = have[u] && di < npx_d && ri < npx_rgb;
+      dd[u] = depth[have[u] ? di : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < BK_CH; u++) {
+      flag[u] = (have[u] && dd[u] != 0) ? 1 : 0;  // HaveXYZ: d ? d*1e-3 : NaN
+      const double z = (double)(float)((double)dd[u] * 1e-3);
+      const int rxu = du[u] < g.W ? du[u] : du[u] - g.W, ryv = du[u] < g.W ? dv[u] : dv[u] + 1;  // pixel the ray index ri names
+      const double rx = (double)rxu * g.fx_inv + g.neg_cx_div_fx;
+      const double ry = (double)ryv * g.fy_inv + g.neg_cy_div_fy;
+      X[u] = z * rx; Y[u] = z * ry; Z[u] = z;
+      if (!flag[u]) { ru[u] = 0.f; rv[u] = 0.f; }
+    }
+    // one block scan for all chunks: their flags travel in 12-bit fields of a 64-bit word (a chunk counts at most 256)
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int u = 0; u < BK_CH; u++) packed |= (unsigned long long)flag[u] << (12 * u);
+    unsigned long long total;
+    const unsigned long long pre = block_excl_scan_256_u64(packed, s_wave64, &total);
+#pragma unroll
+    for (int u = 0; u < BK_CH; u++) {
+      const int pos = base + (int)((pre >> (12 * u)) & 4095);
+      if (flag[u]) {
+        fb.kp_uvs[kbase + pos] = k[u];
+        fb.kp_src[kbase + pos] = (uint16_t)(c0 + u * 256 + tid);
+        fb.kp_rect[kbase + pos] = make_float2(ru[u], rv[u]);
+        fb.kp_track[kbase + pos] = -1;  // frame.cpp:138: not part of a track yet
+        double* xyz = fb.kp_xyz + (kbase + pos) * 3;
+        xyz[0] = X[u]; xyz[1] = Y[u]; xyz[2] = Z[u];
       }
+      base += (int)((total >> (12 * u)) & 4095);
     }
-    int total;
-    const int pos = base + block_excl_scan_256(flag, s_wave, &total);
-    if (flag) {
-      fb.kp_uvs[kbase + pos] = k;
-      fb.kp_src[kbase + pos] = (uint16_t)s;
-      fb.kp_rect[kbase + pos] = make_float2(ru, rv);
-      fb.kp_track[kbase + pos] = -1;  // frame.cpp:138: not part of a track yet
-      double* xyz = fb.kp_xyz + (kbase + pos) * 3;
-      xyz[0] = X; xyz[1] = Y; xyz[2] = Z;
-    }
-    base += total;
   }
   if (tid == 0) fb.kp_cnt[slot * RVO_MAX_LEVELS + lvl] = base;
   // Descriptors of the keypoints that survived: their rows of bk_desc (written by k_fast_grid) are copied into the
-  // level's compact order, one 16-byte piece per thread and trip, five consecutive threads per keypoint.  (Was a kernel
-  // of its own; here it costs no launch.)  The kp_src entries were written by other threads of this workgroup.
+  // level's compact order, one 16-byte piece per thread and trip, five consecutive threads per keypoint, BK_CP trips'
+  // loads in flight at a time.  (Was a kernel of its own; here it costs no launch.)  The kp_src entries were written by
+  // other threads of this workgroup.
   __syncthreads();
-  for (int t = tid; t < base * 5; t += 256) {
-    const int idx = t / 5, piece = t - idx * 5;
-    const size_t src = kbase + fb.kp_src[kbase + idx];
-    reinterpret_cast<uint4*>(fb.kp_desc + (kbase + idx) * RVO_DESC_LEN)[piece] =
-        reinterpret_cast<const uint4*>(fb.bk_desc + src * RVO_DESC_LEN)[piece];
+  for (int t0 = 0; t0 < base * 5; t0 += 256 * BK_CP) {  // (loads with clamped indices for every lane, see above)
+    uint4 v[BK_CP];
+    int idx[BK_CP], piece[BK_CP], src[BK_CP];
+#pragma unroll
+    for (int u = 0; u < BK_CP; u++) {
+      const int t = min(t0 + u * 256 + tid, base * 5 - 1);
+      idx[u] = t / 5; piece[u] = t - idx[u] * 5;
+      src[u] = fb.kp_src[kbase + idx[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < BK_CP; u++) v[u] = reinterpret_cast<const uint4*>(fb.bk_desc + (kbase + src[u]) * RVO_DESC_LEN)[piece[u]];
+#pragma unroll
+    for (int u = 0; u < BK_CP; u++)
+      if (t0 + u * 256 + tid < base * 5) reinterpret_cast<uint4*>(fb.kp_desc + (kbase + idx[u]) * RVO_DESC_LEN)[piece[u]] = v[u];
   }
 }
+
