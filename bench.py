@@ -311,7 +311,7 @@ def main():
                         launches_timed=prof_dom[dom]["calls"],
                         algorithmic_bytes_per_launch=B[dom],
                         note="launch = one whole batch (512 frames / 256 pairs); the launches of four batches are in flight at a time, "
-                             "so a launch's duration includes contention (0.33 ms alone); the kernel is VALU-bound, not "
+                             "so a launch's duration includes contention (0.30 ms alone); the kernel is VALU-bound, not "
                              "HBM-bound (DESIGN.md section 5); dominant = largest VALU issue time per batch")
         # VALU issue roofline (the bound that actually holds for this path): issue time per batch from
         # the committed SQ counters of this same command (a --pmc pass of its own) against the live batch time
