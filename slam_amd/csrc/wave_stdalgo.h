@@ -40,29 +40,33 @@ template <int SHIFT>
 __device__ inline int wave_partition_pivot(uint32_t* a, int first, int last, uint16_t* li, uint16_t* ri) {
   const int lane = threadIdx.x & 63;
   KeyGreater<SHIFT> comp;
-  if (lane == 0) {
-    const int mid = first + (last - first) / 2;
-    stdalgo::move_median_to_first(a, first, first + 1, mid, last - 1, comp);
-  }
+  // __move_median_to_first(first, first+1, mid, last-1) (stl_algo.h:79-98): every lane reads the three candidates and
+  // a[first] at once and takes the decisions of that function; lane 0 performs its swap.  (The indices are distinct:
+  // callers partition ranges of more than three elements.)
+  const int mid = first + (last - first) / 2;
+  const uint32_t vx = a[first + 1], vy = a[mid], vz = a[last - 1], vf = a[first];
+  int mi;
+  if (comp(vx, vy)) mi = comp(vy, vz) ? mid : comp(vx, vz) ? last - 1 : first + 1;
+  else mi = comp(vx, vz) ? first + 1 : comp(vy, vz) ? last - 1 : mid;
+  const uint32_t vm = mi == mid ? vy : mi == last - 1 ? vz : vx;
+  wave_lds_sync();  // every lane has its four values before two of them are exchanged
+  if (lane == 0) { a[first] = vm; a[mi] = vf; }
   wave_lds_sync();
-  const uint32_t pv = a[first] >> SHIFT;
-  // left-stops ascending over [first+1, last)
-  int nl = 0;
-  for (int i0 = first + 1; i0 < last; i0 += 64) {
-    const int i = i0 + lane;
-    const bool stop = i < last && !((a[i] >> SHIFT) > pv);  // !comp(a[i], pivot)
-    const unsigned long long m = __ballot(stop);
-    if (stop) li[nl + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
-    nl += __popcll(m);
-  }
-  // right-stops descending over [first, last)
-  int nr = 0;
-  for (int j0 = last - 1; j0 >= first; j0 -= 64) {
-    const int j = j0 - lane;
-    const bool stop = j >= first && !(pv > (a[j] >> SHIFT));  // !comp(pivot, a[j])
-    const unsigned long long m = __ballot(stop);
-    if (stop) ri[nr + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)j;
-    nr += __popcll(m);
+  const uint32_t pv = vm >> SHIFT;
+  // left-stops ascending over [first+1, last) and right-stops descending over [first, last), 64 positions of each per
+  // trip (their reads are independent and issued together)
+  int nl = 0, nr = 0;
+  for (int o = 0; o < last - first; o += 64) {
+    const int i = first + 1 + o + lane, j = last - 1 - o - lane;
+    const uint32_t ai = i < last ? a[i] : 0u, aj = j >= first ? a[j] : 0u;
+    const bool stopl = i < last && !((ai >> SHIFT) > pv);   // !comp(a[i], pivot)
+    const bool stopr = j >= first && !(pv > (aj >> SHIFT));  // !comp(pivot, a[j])
+    const unsigned long long ml = __ballot(stopl), mr = __ballot(stopr);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (stopl) li[nl + __popcll(ml & below)] = (uint16_t)i;
+    if (stopr) ri[nr + __popcll(mr & below)] = (uint16_t)j;
+    nl += __popcll(ml);
+    nr += __popcll(mr);
   }
   wave_lds_sync();
   // K = #k with Lo[k] < Ro[k]  (Lo ascending, Ro descending: the predicate is monotone)
@@ -128,6 +132,10 @@ __device__ inline void wave_nth_element(uint32_t* a, int nth, int n, uint16_t* l
 #define SORT_QCAP 128
 #endif
 #define SORT_STACK 32
+#ifndef SORT_LOCAL
+#define SORT_LOCAL 64            // right parts up to this size are not published (128: the sort of 920 keys 0.065 ms against 0.057)
+#endif
+#define SORT_LOCAL_FLAG (1 << 30)  // in a private stack entry's depth word: not counted in `pending`
 __device__ inline int sort_ctl_ints(int nwaves) { return 4 + SORT_QCAP * 2 + nwaves * SORT_STACK * 2; }
 
 template <int SHIFT>
@@ -156,10 +164,13 @@ __device__ inline void block_sort(uint32_t* a, int n, uint16_t* li, uint16_t* ri
   int sp = 0;  // entries on this wave's private stack (wave-uniform)
   for (;;) {
     int first, last, depth_limit;
+    bool counted = true;  // the range is one of `pending` (published, or kept back because the queue was full)
     if (sp > 0) {
       sp--;
       const uint32_t seg = (uint32_t)stk[2 * sp];
       first = seg & 0xFFFF; last = seg >> 16; depth_limit = stk[2 * sp + 1];
+      counted = (depth_limit & SORT_LOCAL_FLAG) == 0;
+      depth_limit &= ~SORT_LOCAL_FLAG;
     } else {
       int h = -1;
       uint32_t seg = 0;
@@ -194,7 +205,13 @@ __device__ inline void block_sort(uint32_t* a, int n, uint16_t* li, uint16_t* ri
       }
       --depth_limit;
       const int cut = wave_partition_pivot<SHIFT>(a, first, last, li + first, ri + first);
-      if (last - cut > 16) {
+      if (last - cut > 16 && last - cut <= SORT_LOCAL && sp < SORT_STACK) {
+        // a small right part stays with this wave (no queue traffic: four LDS atomics per range otherwise); nothing it
+        // spawns is ever published, so the other waves need not know about it
+        if (lane == 0) { stk[2 * sp] = (int)((uint32_t)cut | ((uint32_t)last << 16)); stk[2 * sp + 1] = depth_limit | SORT_LOCAL_FLAG; }
+        sp++;
+        wave_lds_sync();
+      } else if (last - cut > 16) {
         int local = 0;
         if (lane == 0) {
           const uint32_t seg = (uint32_t)cut | ((uint32_t)last << 16);
@@ -217,7 +234,7 @@ __device__ inline void block_sort(uint32_t* a, int n, uint16_t* li, uint16_t* ri
     }
     mark_leaf(first, last);  // a <=16 leaf, or a heap-sorted range (already sorted: the stable sort is the identity)
     wave_lds_sync();
-    if (lane == 0) __hip_atomic_fetch_sub(pending, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0 && counted) __hip_atomic_fetch_sub(pending, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();
   // __final_insertion_sort == stable sort of every leaf
