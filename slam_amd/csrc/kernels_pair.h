@@ -977,7 +977,11 @@ __host__ __device__ inline int clique_lds_bytes(int mcap, int cwords) {
 #ifndef CLIQUE_MIN_WAVES
 #define CLIQUE_MIN_WAVES 1
 #endif
-__global__ __launch_bounds__(CLIQUE_WAVES * 64, CLIQUE_MIN_WAVES) void k_clique(PairBufs pb) {
+#define CLIQUE_WALK_MAXN_FWD 2048  // pairs up to this many matches are walked by k_clique_walk (below)
+// WALK = false (the host's choice when every pair fits k_clique_walk, mcap <= CLIQUE_WALK_MAXN): degrees and sort only,
+// a fraction of the registers.
+template <bool WALK>
+__global__ __launch_bounds__(CLIQUE_WAVES * 64, CLIQUE_MIN_WAVES) void k_clique(PairBufs pb, int walk_split) {
   RVO_OCC_SCOPE(10, 1);
   extern __shared__ __align__(16) uint8_t lds[];
   const int pair = blockIdx.x + pb.pair0, tid = threadIdx.x, lane = tid & 63;
@@ -1015,6 +1019,7 @@ __global__ __launch_bounds__(CLIQUE_WAVES * 64, CLIQUE_MIN_WAVES) void k_clique(
   wavealgo::block_sort<16>(keys, N, li, ri, ls, le, tmp, ctl);
   for (int i = tid; i < N; i += CLIQUE_WAVES * 64) pb.order[mb + i] = keys[i];
   if (tid >= 64) return;  // the walk below is one wave; LDS accesses of one wave are ordered, so it needs no barrier
+  if (!WALK || (walk_split && N <= CLIQUE_WALK_MAXN_FWD)) return;  // k_clique_walk takes it from here
 
   // greedy clique, motion_estimate.cpp:529-569, 64 candidates per round.  The 64 candidates' rows of the bit
   // matrix are first copied into LDS with coalesced loads (the sort scratch is dead by now and is reused); lane k
@@ -1133,6 +1138,108 @@ __global__ __launch_bounds__(CLIQUE_WAVES * 64, CLIQUE_MIN_WAVES) void k_clique(
     wavealgo::wave_lds_sync();
   }
   if (lane == 0) res->num_inliers = num_inl;
+}
+
+// The greedy walk of k_clique for pairs of at most CLIQUE_WALK_MAXN matches, as a kernel of its own: ONE wave per pair
+// with next to no LDS, so that it is placed in the wave slot and the registers seven k_fast_grid workgroups leave free on
+// a CU instead of waiting for two of them to retire (k_clique holds 28 KB and 185 VGPRs for the whole walk).  Lane k
+// owns candidate k of the round and keeps its row of the bit matrix in registers; "bit id of my row" for a wave-uniform
+// id is a register selected by a uniform index.  Rows of up to 32 words (N <= 1024) are double-buffered: the next
+// round's rows are loaded while this one is resolved; rows of up to 64 words are loaded at the start of their round.
+// grid (n_pairs), 64 threads.  k_clique has sorted (pb.order) and returns before its own walk for these pairs.
+#define CLIQUE_WALK_MAXN CLIQUE_WALK_MAXN_FWD
+template <int WORDS, bool PREFETCH>
+__device__ inline void clique_walk_rounds(const PairBufs& pb, int pair, int N, uint32_t* acc) {
+  const int lane = threadIdx.x;
+  const size_t mb = (size_t)pair * pb.mcap;
+  const int nw = (N + 31) >> 5, nq = (nw + 3) >> 2;
+  const uint32_t* __restrict__ order = pb.order + mb;
+  const uint32_t* __restrict__ cb = pb.cbits + mb * pb.cwords;
+  const uint32_t cw = (uint32_t)pb.cwords;
+  typedef uint32_t v32_t __attribute__((ext_vector_type(32)));  // (a 64-element vector indexed by a register goes to scratch memory)
+  struct row_t { v32_t h[WORDS / 32]; };
+  auto fetch = [&](int c0, uint32_t* key, row_t* row) {
+    const int m = c0 + lane;
+    *key = m < N ? order[m] : 0u;  // lanes past N carry id 0: a harmless in-range row
+    const uint4* r = reinterpret_cast<const uint4*>(cb + (size_t)(*key & 0xFFFFu) * cw);  // rows are 16-byte aligned, zero beyond column N
+    row_t v;
+#pragma unroll
+    for (int q = 0; q < WORDS / 4; q++) {
+      const uint4 t = q < nq ? r[q] : make_uint4(0u, 0u, 0u, 0u);
+      v.h[q / 8][4 * (q % 8)] = t.x; v.h[q / 8][4 * (q % 8) + 1] = t.y; v.h[q / 8][4 * (q % 8) + 2] = t.z; v.h[q / 8][4 * (q % 8) + 3] = t.w;
+    }
+    *row = v;
+  };
+  uint32_t nkey = 0;
+  row_t nrow;
+  if (PREFETCH) fetch(0, &nkey, &nrow);
+  int num_inl = 0;
+  bool stop = false;
+  for (int c0 = 0; c0 < N && !stop; c0 += 64) {
+    uint32_t key;
+    row_t row;
+    if (PREFETCH) {
+      key = nkey; row = nrow;
+      if (c0 + 64 < N) fetch(c0 + 64, &nkey, &nrow);
+    } else {
+      fetch(c0, &key, &row);
+    }
+    const bool valid = c0 + lane < N;
+    const int id = key & 0xFFFF, deg = (int)(key >> 16);
+    const int kmax = min(64, N - c0);
+    uint32_t bad = 0;
+#pragma unroll
+    for (int w = 0; w < WORDS; w++)
+      if (w < nw) bad |= acc[w] & ~row.h[w / 32][w % 32];
+    const bool ok = valid && bad == 0;
+    // cm bit k of lane j = consistent(candidate j, candidate k): bit id_k of row j
+    uint32_t half[2] = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+      const uint32_t idk = (uint32_t)__builtin_amdgcn_readlane(id, k);
+      uint32_t wv = row.h[0][(idk >> 5) & 31u];  // wave-uniform index
+      if (WORDS > 32) { const uint32_t hi = row.h[WORDS / 32 - 1][(idk >> 5) & 31u]; wv = (idk >> 10) ? hi : wv; }
+      half[k >> 5] |= ((wv >> (idk & 31u)) & 1u) << (k & 31);
+    }
+    const unsigned long long cm = (unsigned long long)half[0] | ((unsigned long long)half[1] << 32);
+    // (the rest is k_clique's round: in-round order dependence by ballots, stop rule, acceptance)
+    unsigned long long alive = __ballot(ok);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (;;) {
+      const bool conf = ((alive >> lane) & 1ull) && ((~cm & alive & lt) != 0ull);
+      const unsigned long long cmask = __ballot(conf);
+      if (!cmask) break;
+      alive &= ~(1ull << (__ffsll((long long)cmask) - 1));
+    }
+    unsigned long long accepted = alive;
+    {
+      const int before = num_inl + __popcll(alive & lt);
+      const unsigned long long sm = __ballot(lane < kmax && deg < before);
+      if (sm) {
+        accepted &= (1ull << (__ffsll((long long)sm) - 1)) - 1ull;
+        stop = true;
+      }
+    }
+    num_inl += __popcll(accepted);
+    if ((accepted >> lane) & 1ull) {
+      atomicOr(&acc[id >> 5], 1u << (id & 31));
+      pb.m_inlier[mb + id] = 1;
+    }
+    wavealgo::wave_lds_sync();
+  }
+  if (lane == 0) pb.result[pair].num_inliers = num_inl;
+}
+__global__ __launch_bounds__(64) void k_clique_walk(PairBufs pb) {
+  RVO_OCC_SCOPE(12, 1);
+  __shared__ uint32_t acc[CLIQUE_WALK_MAXN / 32];
+  const int pair = blockIdx.x + pb.pair0, lane = threadIdx.x;
+  if (!pb.active[pair]) return;
+  const int N = pb.n_matches[pair];
+  if (N == 0 || N > CLIQUE_WALK_MAXN) return;
+  if (lane < CLIQUE_WALK_MAXN / 32) acc[lane] = 0u;
+  wavealgo::wave_lds_sync();
+  if (N <= 1024) clique_walk_rounds<32, true>(pb, pair, N, acc);
+  else clique_walk_rounds<64, false>(pb, pair, N, acc);
 }
 
 // ------------------------------------------------------------------ Gauss-Newton + status

@@ -104,6 +104,7 @@ struct rvo_ctx {
   // stages of the other (what two contexts with rvo_wait_peer did in round 1)
   int stream_groups = 4;         // groups of streams a step is cut into, each a chain on a stream of its own (env RVO_STREAM_GROUPS = 1..kMaxGroups; 0 and 1: one chain per step)
   static constexpr int kMaxGroups = 4;
+  bool clique_split = true;      // env RVO_CLIQUE_SPLIT=0: k_clique does its own greedy walk for every pair
   int stream_group_min = 128;    // fewer streams than this run as one chain (env RVO_STREAM_GROUP_MIN; tests use 2)
   hipEvent_t ev_gfast[kMaxGroups] = {}, ev_gdone[kMaxGroups - 1] = {};
   bool ev_gfast_rec[kMaxGroups] = {};
@@ -398,6 +399,7 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
   for (int i = 0; i < rvo_ctx::kSlotRing; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_pdone[i], hipEventDisableTiming));
   if (const char* e = getenv("RVO_STAGED")) c->staged = atoi(e) != 0;
   if (const char* e = getenv("RVO_STREAM_GROUPS")) c->stream_groups = std::min(std::max(atoi(e), 1), (int)rvo_ctx::kMaxGroups);
+  if (const char* e = getenv("RVO_CLIQUE_SPLIT")) c->clique_split = atoi(e) != 0;
   if (const char* e = getenv("RVO_STREAM_GROUP_MIN")) c->stream_group_min = std::max(2, atoi(e));
   for (int i = 0; i < rvo_ctx::kMaxGroups; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_gfast[i], hipEventDisableTiming));
   for (int i = 0; i < rvo_ctx::kMaxGroups - 1; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_gdone[i], hipEventDisableTiming));

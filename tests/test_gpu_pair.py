@@ -125,21 +125,41 @@ def test_no_features_pair(intr640):
     ctx.close()
 
 
-def test_large_frames_config4(scene):
-    """BASELINE config 4: 1280x960, 4 pyramid levels (large consistency matrix / clique stress)."""
+@pytest.mark.parametrize("thr,per_grid,lo,hi", [(20, 25, 2049, 10**6), (20, 9, 1025, 2048), (20, 4, 300, 1024)])
+def test_large_frames_config4(scene, thr, per_grid, lo, hi):
+    """BASELINE config 4: 1280x960, 4 pyramid levels (large consistency matrix / clique stress).  The three cases put
+    the number of matches into the three ranges the greedy walk treats differently: k_clique's own walk (rows staged in
+    LDS, N > 2048), k_clique_walk with 64-word rows in registers, and with double-buffered 32-word rows."""
     from oracle.pyoracle import Oracle, default_params as odef
     from slam_amd.api import Context, default_params
     intr = synth.default_intrinsics(1280, 960)
-    kw = dict(num_pyramid_levels=4)
+    kw = dict(num_pyramid_levels=4, max_keypoints_per_grid=per_grid)
     ctx = Context(intr, default_params(frame_matcher=True, **kw), max_frames=2, max_pairs=1)
     orc = Oracle(intr, odef(frame_matcher=True, **kw))
     g0, d0, g1, d1, T = synth.make_pair(7, intr, scene)
+    ctx.prepare_frames(np.stack([g0, g1]), np.stack([d0, d1]), thr, [0, 1])
+    orc.prepare(0, g0, d0, thr)
+    orc.prepare(1, g1, d1, thr)
+    rg = ctx.match_pairs([0], [1])[0]
+    ro = orc.match_pair(0, 1)
+    assert lo <= ro["num_matches"] <= hi, ro["num_matches"]
+    compare_pair(ctx, orc, 0, rg, ro)
+    ctx.close()
+
+
+def test_match_pair_without_the_split_clique_walk(scene, intr640, monkeypatch):
+    """RVO_CLIQUE_SPLIT=0: k_clique sorts AND walks (the form before k_clique_walk existed); same results."""
+    from oracle.pyoracle import Oracle, default_params as odef
+    from slam_amd.api import Context, default_params
+    monkeypatch.setenv("RVO_CLIQUE_SPLIT", "0")
+    ctx = Context(intr640, default_params(frame_matcher=True), max_frames=2, max_pairs=1)
+    orc = Oracle(intr640, odef(frame_matcher=True))
+    g0, d0, g1, d1, T = synth.make_pair(3, intr640, scene)
     ctx.prepare_frames(np.stack([g0, g1]), np.stack([d0, d1]), 20, [0, 1])
     orc.prepare(0, g0, d0, 20)
     orc.prepare(1, g1, d1, 20)
     rg = ctx.match_pairs([0], [1])[0]
     ro = orc.match_pair(0, 1)
-    assert ro["num_matches"] > 1500
     compare_pair(ctx, orc, 0, rg, ro)
     ctx.close()
 
