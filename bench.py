@@ -85,7 +85,8 @@ def algorithmic_bytes(geom: dict, stats: dict) -> dict:
     B["refine"] = npair * N * (2 * 100 + 20)
     B["refine_finish"] = npair * N * (20 + 100)
     B["consistency"] = npair * (N * N / 8 + N * 48)
-    B["clique"] = npair * (N * N / 8 + N * 12)
+    B["clique"] = npair * (N * N / 8 + N * 12)   # degrees (the bit matrix once), sort keys in and out
+    B["clique_walk"] = npair * (N * N / 8 + N * 5)  # every candidate's row once, its key, the inlier flags
     B["gauss_newton"] = npair * N * 88
     return B
 
