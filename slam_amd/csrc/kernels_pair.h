@@ -582,6 +582,9 @@ __device__ inline int group16_sum(int v) {
 #ifndef REFINE_THREADS
 #define REFINE_THREADS 128
 #endif
+#ifndef REFINE_GRID_DIV
+#define REFINE_GRID_DIV 2
+#endif
 __global__ __launch_bounds__(REFINE_THREADS, REFINE_MIN_WAVES) void k_refine(FrameBufs fb, FrameGeom g, PairBufs pb) {
   RVO_OCC_SCOPE(7, 16);
   int bx, py;  // XCD-aware: the workgroups of a pair run on one XCD, whose L2 then holds the pair's two images once
@@ -599,8 +602,9 @@ __global__ __launch_bounds__(REFINE_THREADS, REFINE_MIN_WAVES) void k_refine(Fra
   // 16x16 target window around the matched keypoint (rows of 5 aligned dwords): positions within +-3 px of it, i.e.
   // practically every ESM step, read their 10x10 taps from LDS instead of paying an L2 round trip per iteration
   __shared__ __align__(4) uint8_t s_win[REFINE_THREADS / REFINE_GROUP][REFINE_WIN_ROWS * REFINE_WIN_PITCH];
-  if (i_grp < N) {
-  const int i = i_grp;
+  // a workgroup takes every gridDim.x-th set of 8 matches: the grid is sized for a fraction of the slots a pair could
+  // fill (REFINE_GRID_DIV), so few workgroups start only to find nothing to do
+  for (int i = i_grp; i < N; i += (int)gridDim.x * (REFINE_THREADS / REFINE_GROUP)) {
   int lvl = 0;
   for (int l = 1; l < g.levels; l++) if (i >= off[l]) lvl = l;
   const int j = i - off[lvl];
