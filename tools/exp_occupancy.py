@@ -37,7 +37,7 @@ dt = time.perf_counter() - t0
 K, B = 16, 65536
 occ = np.zeros((K, B), np.int32)
 assert L.rvo_debug_occupancy(0, occ.ctypes.data_as(C.c_void_p)) == 0
-names = {1: "pyr", 2: "fast", 3: "buildkp", 4: "desc", 5: "rot", 6: "match", 7: "refine", 8: "finish", 9: "consist", 10: "clique", 11: "gn"}
+names = {1: "pyr", 2: "fast", 3: "buildkp", 4: "desc", 5: "rot", 6: "match", 7: "refine", 8: "finish", 9: "consist", 10: "clique", 11: "gn", 12: "walk"}
 act = np.abs(occ).sum(0) > 0
 idx = np.nonzero(act)[0]
 # buckets wrap modulo 65536: rotate so that the run is contiguous
