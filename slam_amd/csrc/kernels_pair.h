@@ -855,21 +855,30 @@ typedef float f2_t __attribute__((ext_vector_type(2)));
 #define CONS_THREADS 256
 #endif
 #define CONS_PARTS (256 / CONS_THREADS)
+#ifndef CONS_GRID
+// workgroups per pair and part: the ten tiles of up to 1024 matches, one each.  Not a multiple of 8: workgroups are dealt
+// round-robin to the 8 XCDs, and with 8 / 16 per pair every XCD always gets the same tile numbers, some of them never
+// live (measured: 5 / 6 / 8 / 10 / 12 / 16 / 28 per pair: 342 / 344 / 333 / 347 / 343 / 329 / 342 k pairs/s)
+#define CONS_GRID 10
+#endif
 __global__ __launch_bounds__(CONS_THREADS, CONS_MIN_WAVES) void k_consistency(PairBufs pb, EstParams ep) {
   RVO_OCC_SCOPE(9, 4);
   __shared__ float s_c[(CONS_TILE + 32) * 6];
   const int pair = blockIdx.y + pb.pair0;
   if (!pb.active[pair]) return;
   const int N = pb.n_matches[pair];
-  // blockIdx.x enumerates the tile pairs (I, J >= I) of the upper triangle, row tile by row tile: equal work per workgroup
-  // and several times more workgroups than CUs (one workgroup per row tile left the CUs with uneven column counts)
-  const int T = (pb.mcap + 255) / 256;
+  // The tiles (I, J >= I) that hold matches are numbered column tile by column tile (J = 0: (0,0); J = 1: (0,1), (1,1);
+  // ...), so the live ones are the first Tn (Tn + 1) / 2, Tn = ceil(N / 256); the grid has CONS_GRID workgroups per
+  // pair, each taking every CONS_GRID-th live tile (a grid over all tiles of mcap x mcap started mostly workgroups that
+  // had nothing to do: 18 of 28 at 950 matches of 1600).
+  const int Tn = (N + 255) / 256, live_tiles = Tn * (Tn + 1) / 2;
   const int part = blockIdx.x % CONS_PARTS;
-  int tj = blockIdx.x / CONS_PARTS, ti = 0;
-  while (tj >= T - ti) { tj -= T - ti; ti++; }
-  tj += ti;
+  for (int tile = blockIdx.x / CONS_PARTS; tile < live_tiles; tile += gridDim.x / CONS_PARTS) {
+  int tj = 0;
+  while ((tj + 1) * (tj + 2) / 2 <= tile) tj++;
+  const int ti = tile - tj * (tj + 1) / 2;
   const int jstart = ti * 256, jcol = tj * 256;
-  if (jcol >= N) return;  // (jstart <= jcol)
+  __syncthreads();  // the previous tile's readers of s_c are done
   for (int k = threadIdx.x; k < (CONS_TILE + 32) * 6; k += CONS_THREADS) s_c[k] = 0.f;  // padding columns stay finite
   const int lane = threadIdx.x & 63;
   const int i = jstart + part * CONS_THREADS + threadIdx.x;
@@ -899,7 +908,7 @@ __global__ __launch_bounds__(CONS_THREADS, CONS_MIN_WAVES) void k_consistency(Pa
       d[6] = (float)pb.m_xyz[(mb + j0) * 3 + k];
     }
     __syncthreads();
-    if (!wave_live) return;
+    if (wave_live) {
     uint32_t quad[4] = {0u, 0u, 0u, 0u};
     for (int w0 = 0; w0 < nt; w0 += 32) {
       uint32_t word = 0, amb = 0;
@@ -961,7 +970,9 @@ __global__ __launch_bounds__(CONS_THREADS, CONS_MIN_WAVES) void k_consistency(Pa
         }
       }
     }
+    }  // wave_live
   }
+  }  // tiles of this workgroup
 }
 
 // ------------------------------------------------------------------ sort + greedy clique
