@@ -262,6 +262,7 @@ def main():
     gather_backend = None
     gather_ranks = None
     gather_total_ms = None
+    verdict = dict(gather_hung=False, gather_ok=True, gather_over_rccl=False, exit_code=0)
     if world > 1:
         from slam_amd.dist import gather_trajectories_auto
         local = np.stack([np.concatenate([r["pose"].reshape(12), [r["status"], r["num_inliers"]]]) for r in res])
@@ -276,6 +277,8 @@ def main():
         assert allp.shape == (gather_ranks * n_pairs, 14)
         mine = allp[rank * n_pairs:(rank + 1) * n_pairs]
         assert np.array_equal(mine, local)  # every rank finds its own block where its rank says
+        from slam_amd.dist import gather_verdict
+        verdict = gather_verdict(gather_backend, world, bool(gather_t.get("distinct_gpus")))
 
     log("results read, gather done")
     ok = sum(r["status"] == 1 for r in res)
@@ -423,16 +426,22 @@ def main():
                     kernels_note=f"separate pass of {post_steps} steps after the timed region with HIP events around every launch "
                                  "(that instrumentation costs about 7 %); the timed region brackets only the dominant kernel", stats=stats,
                     check=dict(pairs_success=ok, max_abs_pose_err_vs_truth=float(err)),
-                    gather_ms=gather_ms, gather_total_ms=gather_total_ms, gather_backend=gather_backend, gather_ranks=gather_ranks)
+                    gather_ms=gather_ms, gather_total_ms=gather_total_ms, gather_backend=gather_backend, gather_ranks=gather_ranks,
+                    gather_hung=verdict["gather_hung"], gather_ok=verdict["gather_ok"], gather_over_rccl=verdict["gather_over_rccl"])
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
+        # a hung collective, or a gather that bypassed RCCL although every rank has a GPU of its own, must not look green:
+        # the line above is out, the exit code says what happened (slam_amd/dist.py: EXIT_GATHER_HUNG / _NOT_RCCL)
         from slam_amd import dist as rdist
-        if rdist.HUNG:  # a collective attempt timed out: its helper thread still blocks inside RCCL, the line is out
-            os._exit(0)
+        if rdist.HUNG:
+            rdist.finish_after_gather(verdict["exit_code"])
     for c in ctxs:
         c.close()
     if world > 1:
         dist.destroy_process_group()
+        if verdict["exit_code"]:
+            log(f"gather verdict: {verdict}")
+            sys.exit(verdict["exit_code"])
 
 
 if __name__ == "__main__":

@@ -3,6 +3,7 @@
 // loop of PoseGraph::LinearLoopClosure (pose_graph.cpp:85-145) submitted as ONE rvo_match_pairs call, each accepted
 // edge with its information matrix cov.inverse() (pose_graph.cpp:265).
 #pragma once
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -81,6 +82,13 @@ class FrameMatcher {
     for (int i = 0; i < n; i++) tgt[i] = 2 + target_ids[i];
     std::vector<rvo_pair_result> r(n);
     std::vector<double> info((size_t)n * 36);
+    // SetRefFrame + one Match per candidate work on freshly prepared frames (fm.cpp:22-58): the cached ones start
+    // without track ids, and the batch then counts tracks like those calls in order (rvo_get_match_tracks)
+    std::vector<int32_t> fresh(tgt);
+    fresh.push_back(2 + ref_id);
+    std::sort(fresh.begin(), fresh.end());
+    fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
+    if (rvo_reset_tracks(ctx_, (int)fresh.size(), fresh.data())) { fprintf(stderr, "FrameMatcher: %s\n", rvo_last_error()); return 0; }
     if (rvo_match_pairs(ctx_, n, ref.data(), tgt.data(), nullptr, r.data()) || rvo_get_pair_information(ctx_, n, info.data())) {
       fprintf(stderr, "FrameMatcher: %s\n", rvo_last_error());
       return 0;

@@ -101,8 +101,8 @@ void rvo_default_vo_params(rvo_params* out);
 void rvo_default_fm_params(rvo_params* out);
 
 /* Replaces the constructors RGBDVO::RGBDVO (rgbdvo/vo.cpp:22-47) and FrameMatcher::FrameMatcher
- * (rgbdvo/fm.cpp:6-20): builds the undistortion LUT (Camera::MakeXYMap, rgbdvo/camera.cpp:16-67) on the host,
- * uploads it and allocates `max_frames` frame slots and `max_pairs` pair work areas on `device`. */
+ * (rgbdvo/fm.cpp:6-20): builds the undistortion LUT (Camera::MakeXYMap, rgbdvo/camera.cpp:16-67) with one device
+ * kernel (a host copy is kept for rvo_get_lut) and allocates `max_frames` frame slots and `max_pairs` pair work areas on `device`. */
 int rvo_create(const rvo_intrinsics* intr, const rvo_params* params, int device, int max_frames, int max_pairs,
                rvo_ctx** out);
 void rvo_destroy(rvo_ctx* ctx);
@@ -121,7 +121,7 @@ int rvo_set_pair_chunks(rvo_ctx* ctx, int chunks);
 int rvo_wait_peer(rvo_ctx* ctx, rvo_ctx* peer);
 /* No counterpart in the reference: how rvo_match_frames_dev runs its batches.  staged = 1 (default; env RVO_STAGED=0
  * overrides at rvo_create): the stages of a batch run on four HIP streams (frames / initial rotation / pair stages /
- * clique + Gauss-Newton) on one of two sets of pair work areas, so that successive calls pipeline inside ONE context:
+ * clique + Gauss-Newton) on one of four sets of pair work areas, so that successive calls pipeline inside ONE context:
  * the latency-bound tail of batch k runs beside the frame stages of batch k+1.  Rules for the caller: the frame slots of
  * a batch are read by its pair stages, so give consecutive batches different slots (e.g. alternate two halves of the
  * slot range) or the next batch's frame stages wait for them; results of the last two batches stay available
@@ -169,6 +169,12 @@ int rvo_match_pairs_async(rvo_ctx* ctx, int n, const int32_t* ref_slots, const i
 int rvo_match_frames_dev(rvo_ctx* ctx, int n, const uint8_t* gray_dev, const uint16_t* depth_dev, const int32_t* fast_thr,
                          const int32_t* slots, const double* init_pose);
 
+/* Environment read once by rvo_create (deployment switches, each covered by the GPU tests): RVO_STAGED=0 (start with
+ * rvo_set_pipeline(ctx, 0)), RVO_PAIR_CHUNKS=1..4 (rvo_set_pair_chunks), RVO_STREAM_GROUPS=1..4 and
+ * RVO_STREAM_GROUP_MIN (into how many interleaved groups a stream step is cut, and from how many streams on),
+ * RVO_CLIQUE_SPLIT=0 (greedy clique walk inside the sort kernel), RVO_RCCL_LIB (the librccl to open).  Knobs that only
+ * served experiments (stream priorities, LDS padding, work-area set counts) exist in -DRVO_EXPERIMENT_KNOBS builds only. */
+
 /* Front-of-path conversions of the reference's callers, on device memory:
  * ConvertBGR2Gray (helper.cpp:55-64, called at hand_held_demo.cpp:248, pose_graph.cpp:101,128) for n frames of the
  * context's width x height: gray = (u8)(0.114*B + 0.587*G + 0.299*R) in fp64; and DepthToPointCloud::operator()
@@ -210,6 +216,13 @@ int rvo_host_alloc(size_t bytes, void** out);
 int rvo_host_free(void* p);
 int rvo_stream_step_dev(rvo_ctx* ctx, int n_streams, const uint8_t* gray_dev, const uint16_t* depth_dev);
 int rvo_get_stream_results(rvo_ctx* ctx, int n_streams, rvo_stream_result* out);
+/* No counterpart in the reference: after this call stream s reads image index[s] (0 <= index[s] < n_sources) of the
+ * arrays handed to rvo_stream_step_dev, which then hold n_sources images instead of n_streams -- many streams replaying
+ * a few sequences (benchmarks at configs[2]'s size, replicated cameras) without materialising one image per stream.
+ * The step copies the images into the streams' frame slots anyway, so the index costs nothing.  index = NULL or
+ * n_sources <= 0 clears it; rvo_streams_reset clears it too.  The host-buffer step forms refuse to run with an index. */
+int rvo_streams_set_source_index(rvo_ctx* ctx, int n_sources, const int32_t* index /* [n_streams] */);
+
 /* Frame slots stream `stream` currently holds: out[3] = reference, previous, current frame
  * (ref_frame_/prev_frame_/curr_frame_ of rgbdvo/vo.hpp:67-69) -- lets the facade resolve match indices to keypoints. */
 int rvo_get_stream_slots(rvo_ctx* ctx, int stream, int32_t* out);
@@ -224,7 +237,7 @@ int rvo_stream_results_dev(rvo_ctx* ctx, void** dev_ptr);
 #define RVO_TRAJ_DOUBLES 16
 int rvo_streams_record(rvo_ctx* ctx, int max_steps);
 int rvo_trajectories_dev(rvo_ctx* ctx, void** dev_ptr, int32_t* steps_recorded, int32_t* max_steps);
-/* out[n_streams][steps][RVO_TRAJ_DOUBLES]; synchronises */
+/* out[n_streams][steps][RVO_TRAJ_DOUBLES] (16 doubles per row, see above); synchronises */
 int rvo_get_trajectories(rvo_ctx* ctx, int n_streams, int steps, double* out);
 
 /* ---- multi-GPU: the final trajectory gather.  No counterpart in the reference (one process,
@@ -259,12 +272,19 @@ int rvo_get_matches(rvo_ctx* ctx, int pair, int cap, int32_t* ints, double* dbl)
  * reference keypoint without a track opens one, the match and the target keypoint take its id, and the target
  * keypoints of matches that end up as outliers lose theirs again (motion_estimate.cpp:216-222).  A batch of
  * rvo_match_pairs / rvo_match_frames_dev counts tracks like ONE MotionEstimator working through its pairs in order
- * (FrameMatcher, fm.hpp:41) as long as no frame slot is used by two pairs of the batch; every stream of
- * rvo_stream_step has a counter of its own (RGBDVO's estimator, vo.hpp:96).  Returns the number of rows written. */
+ * (FrameMatcher, fm.hpp:41): rvo_match_pairs walks the pairs in order when a frame slot is named by two of them (one
+ * reference keyframe against many candidates), so a reference keypoint's track is opened by the first pair that matches
+ * it and reused by the later ones; rvo_match_frames_dev requires distinct slots.  Every stream of rvo_stream_step has a
+ * counter of its own (RGBDVO's estimator, vo.hpp:96).  Returns the number of rows written. */
 int rvo_get_match_tracks(rvo_ctx* ctx, int pair, int cap, int32_t* track_ids);
 /* KeypointData::track_id of the keypoints of a slot's level (rgbdvo/feature.hpp:75; -1 = none, frame.cpp:138), rows as
  * rvo_get_keypoints writes them.  Returns the number of rows written. */
 int rvo_get_keypoint_tracks(rvo_ctx* ctx, int slot, int level, int32_t* track_ids);
+/* KeypointData::track_id = -1 for every keypoint of the n slots, as after Frame::PrepareFrame (rgbdvo/frame.cpp:138).
+ * For frames that stay prepared on the device where the reference's caller would prepare them again: the batched loop
+ * closure (rgbdvo::FrameMatcher::MatchCachedKeyFrames) calls it on the reference keyframe and the candidates, so its
+ * track ids equal those of SetRefFrame + one Match per candidate (rgbdvo/fm.cpp:22-58, pose_graph.cpp:104,132).  Enqueues only. */
+int rvo_reset_tracks(rvo_ctx* ctx, int n, const int32_t* slots);
 int rvo_get_lut(rvo_ctx* ctx, float* xmap, float* ymap);
 
 /* Self-test hook (no counterpart in the reference): runs the wave-parallel replay of libstdc++'s std::sort

@@ -51,9 +51,9 @@ SYMBOLS = [
     "rvo_stream_step", "rvo_stream_step_dev", "rvo_get_stream_results", "rvo_stream_results_dev",
     "rvo_get_stream_slots",
     "rvo_get_level_info", "rvo_get_level_image", "rvo_get_grid_keypoints", "rvo_get_keypoints",
-    "rvo_stream_step_host_async", "rvo_wait_upload", "rvo_host_alloc", "rvo_host_free", "rvo_get_descriptors", "rvo_get_matches", "rvo_get_match_tracks", "rvo_get_keypoint_tracks", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_select", "rvo_profile_read",
+    "rvo_stream_step_host_async", "rvo_wait_upload", "rvo_host_alloc", "rvo_host_free", "rvo_get_descriptors", "rvo_get_matches", "rvo_get_match_tracks", "rvo_get_keypoint_tracks", "rvo_reset_tracks", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_select", "rvo_profile_read",
     "rvo_selftest_stdalgo", "rvo_bgr_to_gray_dev", "rvo_depth_to_point_cloud_dev", "rvo_get_pair_information", "rvo_get_pair_information_noalloc", "rvo_set_pair_chunks", "rvo_wait_peer",
-    "rvo_streams_record", "rvo_trajectories_dev", "rvo_get_trajectories",
+    "rvo_streams_record", "rvo_streams_set_source_index", "rvo_trajectories_dev", "rvo_get_trajectories",
     "rvo_set_pipeline", "rvo_get_batch_results", "rvo_comm_get_unique_id", "rvo_comm_create", "rvo_comm_destroy", "rvo_gather_trajectories",
 ]
 TRAJ_DOUBLES = 16   # RVO_TRAJ_DOUBLES
@@ -137,6 +137,7 @@ def load():
     L.rvo_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.rvo_host_free.argtypes = [vp]
     L.rvo_get_keypoint_tracks.argtypes = [vp, ip, ip, vp]
+    L.rvo_reset_tracks.argtypes = [vp, ip, vp]
     L.rvo_get_lut.argtypes = [vp, vp, vp]
     L.rvo_profile_enable.argtypes = [vp, ip]
     L.rvo_profile_select.argtypes = [vp, C.c_char_p]
@@ -145,6 +146,7 @@ def load():
     L.rvo_set_pipeline.argtypes = [vp, ip]
     L.rvo_get_batch_results.argtypes = [vp, ip, ip, vp]
     L.rvo_streams_record.argtypes = [vp, ip]
+    L.rvo_streams_set_source_index.argtypes = [vp, ip, vp]
     L.rvo_trajectories_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rvo_get_trajectories.argtypes = [vp, ip, ip, vp]
     L.rvo_comm_get_unique_id.argtypes = [vp]

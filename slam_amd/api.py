@@ -239,6 +239,11 @@ class Context:
             self._chk(rc)
         return out
 
+    def reset_tracks(self, slots):
+        """track_id = -1 on every keypoint of these slots, as after Frame::PrepareFrame (frame.cpp:138); async."""
+        slots = _i32(slots)
+        self._chk(self.L.rvo_reset_tracks(self.h, len(slots), _ptr(slots)))
+
     def lut(self):
         x = np.empty((self.H, self.W), np.float32)
         y = np.empty((self.H, self.W), np.float32)
@@ -267,6 +272,14 @@ class Context:
 
     def stream_step_dev(self, gray_ptr: int, depth_ptr: int, n_streams):
         self._chk(self.L.rvo_stream_step_dev(self.h, n_streams, C.c_void_p(gray_ptr), C.c_void_p(depth_ptr)))
+
+    def streams_set_source_index(self, n_sources: int, index):
+        """Stream s reads image index[s] of the (then n_sources-image) arrays given to stream_step_dev; None clears."""
+        if index is None:
+            self._chk(self.L.rvo_streams_set_source_index(self.h, 0, None))
+        else:
+            index = _i32(index)
+            self._chk(self.L.rvo_streams_set_source_index(self.h, n_sources, _ptr(index)))
 
     def stream_results(self, n_streams):
         out = (StreamResult * n_streams)()
@@ -363,6 +376,8 @@ class FrameMatcher:
             if not 0 <= int(i) < self.max_keyframes:
                 raise RvoError(f"keyframe id {i} out of range")
         t = [2 + int(i) for i in target_ids]
+        # SetRefFrame + one Match per candidate work on freshly prepared frames (fm.cpp:22-58): no track ids yet
+        self.ctx.reset_tracks(sorted({2 + ref_id, *t}))
         res = self.ctx.match_pairs([2 + ref_id] * len(t), t)
         info = self.ctx.pair_information(len(t))
         out = []

@@ -96,13 +96,15 @@ __device__ inline int block_excl_scan(int v, int* s_wave, int* total) {
 // (depth is only sampled at keypoints and refined matches, ~5 KB of the 614 KB image).
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_ingest(FrameBufs fb, FrameGeom g, const uint8_t* __restrict__ gray,
-                                                const uint16_t* __restrict__ depth, const int32_t* __restrict__ slots, int copy_depth, int copy_gray) {
+                                                const uint16_t* __restrict__ depth, const int32_t* __restrict__ slots, int copy_depth, int copy_gray,
+                                                const int32_t* __restrict__ src_index /* null: frame f reads image f */) {
   const int f = blockIdx.y;
   const int slot = slots[f];
   if (slot < 0) return;
   const size_t npx = (size_t)g.W * g.H, ndp = (size_t)g.Wd * g.Hd;
-  const uint8_t* gs = gray + f * npx;
-  const uint16_t* dsrc = depth + f * ndp;
+  const int fsrc = src_index ? src_index[f] : f;  // rvo_streams_set_source_index: several streams replay one image
+  const uint8_t* gs = gray + fsrc * npx;
+  const uint16_t* dsrc = depth + fsrc * ndp;
   uint8_t* gd = fb.img + (size_t)slot * g.img_bytes + g.lv[0].img_off;
   uint16_t* dd = fb.depth + (size_t)slot * ndp;
   const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;

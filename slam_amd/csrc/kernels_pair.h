@@ -1440,6 +1440,58 @@ __global__ __launch_bounds__(256) void k_track_assign(FrameBufs fb, FrameGeom g,
   }
 }
 
+// mode 1 when two pairs of the batch share a frame slot (the batched loop closure: one reference keyframe against all
+// candidates, FrameMatcher::SetRefFrame once + Match per candidate): the pairs are NOT independent then -- the first pair
+// that matches a reference keypoint opens its track and the later ones reuse it (motion_estimate.cpp:385-390) -- so one
+// workgroup walks the pairs in order, each pair in parallel over its matches (a keypoint occurs in one match per pair).
+// grid 1, 256 threads.
+__global__ __launch_bounds__(256) void k_track_serial(FrameBufs fb, FrameGeom g, PairBufs pb, int n_pairs, const int32_t* ctr_in,
+                                                      int32_t* ctr_out) {
+  __shared__ int s_wave[8];
+  const int tid = threadIdx.x;
+  int ctr = ctr_in[0];
+  for (int pair = 0; pair < n_pairs; pair++) {
+    if (!pb.active[pair]) {
+      if (tid == 0) pb.new_tracks[pair] = 0;
+      continue;
+    }
+    const int N = pb.n_matches[pair], rs = pb.ref_slot[pair], ts = pb.tgt_slot[pair];
+    const size_t mb = (size_t)pair * pb.mcap;
+    int base = 0;
+    for (int c0 = 0; c0 < N; c0 += 256) {
+      const int i = c0 + tid;
+      int cur = 0, flag = 0, off = 0;
+      if (i < N) {
+        off = g.lv[pb.m_level[mb + i]].kp_off;
+        cur = fb.kp_track[(size_t)rs * g.kp_total + off + pb.m_ref[mb + i]];
+        flag = cur < 0;
+      }
+      int total;
+      const int pos = base + block_excl_scan_256(flag, s_wave, &total);
+      if (i < N) {
+        const int id = flag ? ctr + pos : cur;
+        pb.m_track[mb + i] = id;
+        fb.kp_track[(size_t)rs * g.kp_total + off + pb.m_ref[mb + i]] = id;
+        fb.kp_track[(size_t)ts * g.kp_total + off + pb.m_tgt[mb + i]] = pb.m_inlier[mb + i] ? id : -1;
+      }
+      base += total;
+    }
+    if (tid == 0) pb.new_tracks[pair] = base;
+    ctr += base;
+    __threadfence_block();
+    __syncthreads();  // the next pair reads the ids this one wrote
+  }
+  if (tid == 0) ctr_out[0] = ctr;
+}
+
+// "These frames were just prepared" as far as tracks go (KeypointData::track_id = -1, frame.cpp:138), for frames that
+// stay cached on the device where the reference would call SetRefFrame / Match on fresh Frame objects.
+// grid (ceil(kp_total / 256), n), 256 threads.
+__global__ __launch_bounds__(256) void k_reset_tracks(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < g.kp_total) fb.kp_track[(size_t)slots[blockIdx.y] * g.kp_total + i] = -1;
+}
+
 // ------------------------------------------------------------------ edge information for the pose graph
 // PoseGraphOptimizer::AddEdge (pose_graph.cpp:254-270): info = edge.covariance.inverse(), one 6x6 partial-pivot
 // inverse per accepted pair.  One thread per pair; pairs without a valid estimate get zeros.

@@ -75,6 +75,8 @@ struct rvo_ctx {
   rvo_stream_result* d_stream_res = nullptr;
   int n_streams = 0;
   int32_t* d_sslots = nullptr;  // [2n]: current slot (-1 = warm-up skip), FAST threshold (device-written)
+  int32_t* d_src_index = nullptr;  // rvo_streams_set_source_index: [stream] image of the step's arrays the stream reads
+  int src_sources = 0;             // images those arrays hold then (0: no index, stream s reads image s)
   double* d_traj = nullptr;     // rvo_streams_record: [n_streams][traj_cap][RVO_TRAJ_DOUBLES]
   int traj_cap = 0, traj_steps = 0, traj_streams = 0;
   double* d_pinit = nullptr;
@@ -91,7 +93,7 @@ struct rvo_ctx {
   static const int kAux = 3;
   hipStream_t aux[kAux] = {};
   hipEvent_t ev_fork = nullptr, ev_join[kAux] = {};
-  bool rot_side = true;  // k_init_rotation on a side stream (env RVO_ROT_SIDE=0: on the batch's own stream)
+  bool rot_side = true;  // k_init_rotation on a side stream (experiment builds, env RVO_ROT_SIDE=0: on the batch's own stream)
   hipEvent_t ev_mid = nullptr;  // recorded after k_fast_grid of a batch (rvo_wait_peer)
   int pair_chunks = 2;
   // Staged pipeline of rvo_match_frames_dev: the stages of successive batches run on four streams
@@ -109,11 +111,16 @@ struct rvo_ctx {
   hipEvent_t ev_gfast[kMaxGroups] = {}, ev_gdone[kMaxGroups - 1] = {};
   bool ev_gfast_rec[kMaxGroups] = {};
   int group_pending = 0;         // groups of the latest step (beyond the first) not yet joined into the main stream
+  // Work that entry points outside the two pipelines put on the main stream (conversions, prepared frames, pair batches,
+  // a peer wait) must precede what the pipelines run on the OTHER streams: main_epoch counts such calls, and a pipeline
+  // whose last fork saw an older epoch orders its side streams after the main stream again (one event) before it goes on.
+  long long main_epoch = 0, groups_epoch = -1, staged_epoch = -1;
   bool staged = true;            // env RVO_STAGED=0 / rvo_set_pipeline(ctx, 0): the chunked single-chain form
   static const int kPairSets = 4;
-  int pair_sets = kPairSets;     // env RVO_PAIR_SETS (2..kPairSets): experiments
+  int pair_sets = kPairSets;     // experiment builds: env RVO_PAIR_SETS (2..kPairSets)
   PairBufs pbs[kPairSets];
   long long batch_id = 0;        // staged batches submitted so far
+  long long staged_valid_from = 0;  // staged batches before this one had their work areas reused by a non-staged call
   int staged_pending = 0;        // bit s: set s has staged work the main stream has not been ordered after yet
   hipEvent_t ev_f[kPairSets] = {}, ev_p[kPairSets] = {}, ev_t[kPairSets] = {}, ev_pyr2[kPairSets] = {}, ev_rot2[kPairSets] = {};
   bool ev_p_rec[kPairSets] = {}, ev_t_rec[kPairSets] = {};
@@ -354,10 +361,12 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
   fl.cand_cap = std::max(fl.list_cap * 2, ((g.gw + 2) * (g.gh + 2) + 1) / 2);
   fl.off_misc = fl.off_list + round_up(fl.cand_cap * 2, 16);
   fl.total = fl.off_misc + 64 + round_up((g.gw * g.gh + 31) / 32 * 4, 16);
-  if (const char* e = getenv("RVO_FAST_LDS_MIN")) {  // experiments: fewer k_fast_grid workgroups per CU
+#ifdef RVO_EXPERIMENT_KNOBS  // one-off builds only (tools/exp_variant.sh)
+  if (const char* e = getenv("RVO_FAST_LDS_MIN")) {  // fewer k_fast_grid workgroups per CU
     fprintf(stderr, "k_fast_grid LDS %d -> at least %d bytes\n", fl.total, atoi(e));
     fl.total = std::max(fl.total, round_up(atoi(e), 16));
   }
+#endif
   if (fl.total > 150 * 1024 || g.gw + 2 > 255 || g.gh + 2 > 255 || (g.gw + 2) * (g.gh + 2) > 64 * 256 ||
       ((g.gw + 7) / 4 + 1) * (g.gh + 2) > 16 * 256) {  // phase A of k_fast_grid: <= 16 four-pixel groups per thread
     g_err = "grid cell too large for LDS"; return RVO_E_UNSUPPORTED; }
@@ -375,9 +384,11 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
   // They must all have the SAME priority: with the frame stages at normal and the tail at high priority, a context
   // stopped making progress as soon as two more processes used the GPU (its high-priority queues, blocked on events
   // of the normal ones, kept those from being scheduled; tools/exp_three_procs.py).
-  // RVO_STREAM_PRIORITY = one letter per stream (own, aux0, aux1, aux2; h greatest, n normal, l least): experiments.
-  const char* prio_env = getenv("RVO_STREAM_PRIORITY");
-  const char* prio = (prio_env && strlen(prio_env) == 1 + rvo_ctx::kAux) ? prio_env : "hhhh";
+  const char* prio = "hhhh";
+#ifdef RVO_EXPERIMENT_KNOBS  // one-off builds only: mixed priorities can hang the context (see above), so the product has no such knob
+  // RVO_STREAM_PRIORITY = one letter per stream (own, aux0, aux1, aux2; h greatest, n normal, l least)
+  if (const char* prio_env = getenv("RVO_STREAM_PRIORITY")) if (strlen(prio_env) == 1 + rvo_ctx::kAux) prio = prio_env;
+#endif
   int least = 0, greatest = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
   auto prio_of = [&](char ch) { return ch == 'h' ? greatest : ch == 'l' ? least : 0; };
@@ -406,7 +417,9 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
   c->slot_reader.assign((size_t)max_frames, -1);
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
+#ifdef RVO_EXPERIMENT_KNOBS
   if (const char* e = getenv("RVO_ROT_SIDE")) c->rot_side = atoi(e) != 0;
+#endif
   for (int i = 0; i < 2; i++) {
     HIPCHK(hipEventCreateWithFlags(&c->ev_pyr[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_rot[i], hipEventDisableTiming));
@@ -512,6 +525,7 @@ void rvo_destroy(rvo_ctx* c) {
 // Orders the context's main stream after every staged batch still in flight (their pair and tail stages run on other
 // streams): called by every entry point that touches pair work areas or frame slots outside the staged pipeline.
 static int join_staged(rvo_ctx* c, bool keep_groups = false) {
+  if (!keep_groups) c->main_epoch++;  // every caller but the grouped stream step goes on to use the main stream
   if (c->group_pending && !keep_groups) {  // the other groups of the latest stream step (rvo_stream_step_dev)
     for (int i = 0; i < c->group_pending; i++) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_gdone[i], 0));
     c->group_pending = 0;
@@ -592,13 +606,13 @@ static int ensure_stage(rvo_ctx* c, int n) {
 // read in place; the gray image too when its rows already have the level-0 stride and 16-byte alignment, and then
 // the launch only records the two pointers per slot.
 static int launch_ingest_on(rvo_ctx* c, hipStream_t st, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots,
-                            int copy) {
+                            int copy, const int32_t* d_src_index = nullptr) {
   const FrameGeom& g = c->g;
   const bool vec = (g.W % 16 == 0) && (((size_t)g.Wd * g.Hd) % 8 == 0) && (((uintptr_t)gray & 15) == 0) && (((uintptr_t)depth & 15) == 0);
   const int copy_gray = (copy || g.lv[0].stride != g.W || ((uintptr_t)gray & 15) != 0) ? 1 : 0;
   const dim3 grid(copy_gray ? 16 : 1, n);
-  if (vec) LAUNCH_ON(c, st, "ingest", k_ingest<true>, grid, dim3(256), 0, c->fb, g, gray, depth, d_slots, copy, copy_gray);
-  else LAUNCH_ON(c, st, "ingest", k_ingest<false>, grid, dim3(256), 0, c->fb, g, gray, depth, d_slots, copy, copy_gray);
+  if (vec) LAUNCH_ON(c, st, "ingest", k_ingest<true>, grid, dim3(256), 0, c->fb, g, gray, depth, d_slots, copy, copy_gray, d_src_index);
+  else LAUNCH_ON(c, st, "ingest", k_ingest<false>, grid, dim3(256), 0, c->fb, g, gray, depth, d_slots, copy, copy_gray, d_src_index);
   return RVO_OK;
 }
 static int launch_ingest(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots) {
@@ -664,6 +678,7 @@ int rvo_prepare_frames_dev(rvo_ctx* c, int n, const uint8_t* gray, const uint16_
   for (int i = 0; i < n; i++)
     if (thr[i] < 0 || thr[i] > 255) { g_err = "rvo_prepare_frames: FAST threshold outside 0..255"; return RVO_E_INVALID; }
   HIPCHK(hipSetDevice(c->device));
+  c->main_epoch++;
   { const int rc0 = wait_slots_free(c, c->stream, n, slots); if (rc0) return rc0; }
   std::vector<int32_t> args(2 * (size_t)n);
   memcpy(args.data(), slots, n * 4);

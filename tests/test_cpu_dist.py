@@ -105,3 +105,31 @@ def test_vertex_file_cpp_and_python_agree(tmp_path):
     assert subprocess.call([exe, "read", p_py]) == 1
     with pytest.raises(ValueError):
         vertex_io.load_vertices(p_py)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """A box without a loadable librccl: rvo_comm_get_unique_id and rvo_comm_create(world > 1) must come back with
+    RVO_E_UNSUPPORTED and a message (the fall-back to torch's nccl / gloo in gather_trajectories_auto depends on it).
+    Runs in a child process: the library caches its dlopen verdict.  No GPU needed -- the loader is asked before any device call."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from slam_amd import _lib\n"
+        "L = _lib.load()\n"
+        "buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()\n"
+        "rc = L.rvo_comm_get_unique_id(buf)\n"
+        "msg = L.rvo_last_error().decode()\n"
+        "print(rc, '|', msg)\n"
+        "rc2 = L.rvo_comm_get_unique_id(buf)\n"
+        "print(rc2, '|', L.rvo_last_error().decode())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RVO_RCCL_LIB="/nonexistent/librccl.so.1", RVO_HIP_RUNTIME="system")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    for line in lines[-2:]:
+        rc, msg = line.split("|", 1)
+        assert int(rc) == -2, line  # RVO_E_UNSUPPORTED
+        assert "librccl not found" in msg and "/nonexistent/librccl.so.1" in msg, line

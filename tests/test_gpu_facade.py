@@ -67,15 +67,37 @@ def test_cpp_facade_matches_python_mirror(scene, tmp_path):
     orc = pyoracle.Oracle(intr, pyoracle.default_params(frame_matcher=True))
     orc.prepare(0, seq[N - 1][0], seq[N - 1][1], lc.thr)
     n_valid = 0
-    for tid, valid, motion, cov, info in edges:
+    reused = 0
+    for k, (tid, valid, motion, cov, info) in enumerate(edges):
         orc.prepare(1, seq[tid][0], seq[tid][1], lc.thr)
         ro = orc.match_pair(0, 1)
         assert valid == (ro["status"] == 1), tid
         assert np.abs(motion[:3] - ro["pose"]).max() < 1e-9, tid
+        # track ids (motion_estimate.cpp:380-391): every pair of the batch names the SAME reference slot, so the first
+        # candidate that matches a reference keypoint opens its track and the later ones reuse it -- the batch is walked
+        # in pair order (k_track_serial) and equals SetRefFrame + one Match per candidate on the oracle
+        n = ro["num_matches"]
+        to = orc.match_tracks(n)
+        assert np.array_equal(lc.ctx.match_tracks(k, n), to), tid
+        if k:
+            reused += int((to < tracks_before).sum())
+        tracks_before = orc.num_tracks()
         if valid:
             n_valid += 1
             np.testing.assert_allclose(cov, ro["cov"], rtol=1e-6, atol=1e-12)
             np.testing.assert_allclose(info, pyoracle.information(ro["cov"]), rtol=1e-5)
+    assert reused > 100  # later candidates did continue tracks the earlier ones opened
+    for l in range(3):  # the reference keyframe's keypoints hold the ids all candidates left behind
+        assert np.array_equal(lc.ctx.keypoint_tracks(2 + N - 1, l), orc.keypoint_tracks(0, l))
+    # a second closure on the same cached frames starts from fresh frames again (rvo_reset_tracks), with the estimator's
+    # running track counter (the oracle's FrameMatcher likewise keeps _num_tracks)
+    edges2 = lc.MatchCachedKeyFrames(0, [1, 2])
+    orc.prepare(0, seq[0][0], seq[0][1], lc.thr)
+    for k, tid in enumerate([1, 2]):
+        orc.prepare(1, seq[tid][0], seq[tid][1], lc.thr)
+        ro = orc.match_pair(0, 1)
+        assert edges2[k][1] == (ro["status"] == 1)
+        assert np.array_equal(lc.ctx.match_tracks(k, ro["num_matches"]), orc.match_tracks(ro["num_matches"])), tid
     assert n_valid >= 3
     for l, (tid, valid, motion, cov, info) in zip(lce, edges):
         assert int(l[1]) == tid and int(l[2]) == int(valid)

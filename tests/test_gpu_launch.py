@@ -66,4 +66,27 @@ def test_run_streams_gpus_2_end_to_end(tmp_path):
     assert d["n_gpus"] == 2 and d["gather_ranks"] == 2 and d["streams"] == 16
     assert d["estimates_ok"] == d["estimates"] == 16 * 4
     assert d["max_abs_pose_err_vs_truth"] < 5e-3
-    assert os.path.exists(tmp_path / "stream_0000.vertices")
+    assert d["gather_ok"] and not d["gather_hung"] and d["unique_sequences"] == 16 and d["peak_host_rss_gb"] > 0
+    # f4: the vertex files hold, byte for byte, the gathered trajectories (pose_graph.cpp:147-199's record layout), read
+    # back by the Python reader and by the C++ one a caller of the facade would use (include/rgbdvo/vertex_io.hpp)
+    import numpy as np
+    from slam_amd import vertex_io
+    allt = np.load(tmp_path / "trajectories_first8.npy")  # [8, frames, 16] rows of the gathered array
+    exe = str(tmp_path / "test_vertex_io")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "test_vertex_io.cpp")])
+    for s_ in (0, 7):
+        fn = str(tmp_path / f"stream_{s_:04d}.vertices")
+        assert os.path.getsize(fn) == 5 * 144
+        ids, poses = vertex_io.load_vertices(fn)
+        assert ids.tolist() == list(range(5))
+        assert np.array_equal(poses[:, :3, :], allt[s_, :, :12].reshape(5, 3, 4))
+        assert np.array_equal(poses[:, 3, :], np.tile([0.0, 0.0, 0.0, 1.0], (5, 1)))
+        cpp = subprocess.run([exe, "read", fn], capture_output=True, text=True, timeout=60)
+        assert cpp.returncode == 0, cpp.stderr
+        rows = [l.split() for l in cpp.stdout.splitlines() if not l.startswith("by_id")]
+        assert [int(r[0]) for r in rows] == list(range(5))
+        assert np.array_equal(np.array([[float(x) for x in r[1:]] for r in rows]), allt[s_, :, :12])
+    # the estimates are real ones: frame 0 is the identity, later frames moved and succeeded
+    assert np.array_equal(allt[0, 0, :12].reshape(3, 4), np.eye(4)[:3]) and (allt[:, 1:, 12] == 1).all()
+    assert np.abs(allt[0, -1, :12].reshape(3, 4) - np.eye(4)[:3]).max() > 1e-4

@@ -265,3 +265,100 @@ def test_stream_step_host_async_equals_blocking_step(scene, intr640):
         if pinned:
             for h in hg + hd:
                 h.free()
+
+
+def test_bgr_conversion_feeds_grouped_stream_steps(scene, intr640, monkeypatch):
+    """rvo_bgr_to_gray_dev writes the gray images on the context's stream and rvo_stream_step_dev reads them at once
+    (include/rvo.h) -- with the step cut into groups that run on streams of their own, every group must be
+    ordered after the conversion, step after step, although nothing is synchronised in between and the SAME gray buffer
+    is rewritten for every frame (a group that started early would ingest a half-written or stale image).  Checked
+    against OracleVO fed with the oracle's own ConvertBGR2Gray (helper.cpp:55-64) of the same BGR frames."""
+    import torch
+    from oracle import pyoracle
+    from oracle.pyoracle import Oracle, OracleVO, default_params as odef
+    from slam_amd.api import Context, default_params
+    monkeypatch.setenv("RVO_STREAM_GROUP_MIN", "2")
+    monkeypatch.setenv("RVO_STREAM_GROUPS", "4")
+    n, T, warm = 8, 9, 1
+    rng = np.random.default_rng(5)
+    seqs = [list(synth.make_sequence(T, seed=80 + s, intr=intr640, scene=scene)) for s in range(n)]
+    # colour frames whose gray conversion differs from every channel: B, G, R = g - 9, g + 3, g + 5 (clipped) + noise
+    bgr = np.empty((T, n, 480, 640, 3), np.uint8)
+    for t in range(T):
+        for s in range(n):
+            g = seqs[s][t][0].astype(np.int16)
+            for ch, off in enumerate((-9, 3, 5)):
+                bgr[t, s, :, :, ch] = np.clip(g + off + rng.integers(-2, 3, g.shape), 0, 255)
+    gray_expect = pyoracle.bgr_to_gray(bgr)  # [T, n, H, W]
+    d_bgr = torch.from_numpy(bgr).cuda()
+    d_depth = torch.from_numpy(np.stack([np.stack([seqs[s][t][1] for s in range(n)]) for t in range(T)]).view(np.int16)).cuda()
+    d_gray = torch.zeros((n, 480, 640), dtype=torch.uint8, device="cuda")  # ONE buffer, rewritten for every frame
+    torch.cuda.synchronize()
+    ctx = Context(intr640, default_params(warmup_frames=warm), max_frames=3 * n, max_pairs=n)
+    ctx.streams_reset(n)
+    ctx.streams_record(T)
+    for t in range(T):  # nothing synchronises inside this loop
+        ctx.bgr_to_gray_dev(n, d_bgr[t].data_ptr(), d_gray.data_ptr())
+        ctx.stream_step_dev(d_gray.data_ptr(), d_depth[t].data_ptr(), n)
+    traj = ctx.trajectories(n, T)
+    for s in range(n):
+        ovo = OracleVO(Oracle(intr640, odef(warmup_frames=warm)))
+        for t in range(T):
+            ro = ovo.process(gray_expect[t, s], seqs[s][t][1])
+            assert (traj[s, t, 12], traj[s, t, 13], traj[s, t, 14]) == (ro["status"], ro["num_inliers"], ro["rc"]), (s, t)
+            assert np.abs(traj[s, t, :12].reshape(3, 4) - ro["pose"]).max() < 1e-8, (s, t)
+        assert ro["status"] == 1
+        ovo.close()
+    ctx.close()
+
+
+def test_512_streams_on_one_context_configs2_default_shape(intr640):
+    """BASELINE configs[2] per GPU in the shipped default arrangement (tools/run_streams.py): 512 streams on ONE context,
+    the step cut into four groups of 128 by the library, 16 distinct sequences resident on the device once and replayed
+    through rvo_streams_set_source_index (stream s plays sequence s % 16), trajectories kept on the device, NOTHING
+    synchronised between the steps.  A sample of streams (first / last of every group and two inside) is compared with
+    OracleVO frame by frame; every other stream must equal, bit for bit, the stream that plays the same sequence."""
+    import torch
+    from oracle.pyoracle import Oracle, OracleVO, default_params as odef
+    from slam_amd.api import Context, default_params
+    S, T, U, warm = 512, 7, 16, 2
+    seqs = [list(synth.make_sequence(T, seed=140 + u, intr=intr640, scene=synth.PlaneScene(seed=u % 4),
+                                     invalid_frac=0.1 if u % 5 == 0 else 0.0)) for u in range(U)]
+    ug = torch.from_numpy(np.stack([np.stack([seqs[u][t][0] for u in range(U)]) for t in range(T)])).cuda()  # [T,U,H,W]
+    ud = torch.from_numpy(np.stack([np.stack([seqs[u][t][1] for u in range(U)]) for t in range(T)]).view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    ctx = Context(intr640, default_params(warmup_frames=warm), max_frames=3 * S, max_pairs=S)
+    ctx.streams_reset(S)
+    index = np.arange(S) % U
+    with pytest.raises(Exception):
+        ctx.streams_set_source_index(U, index + 1)  # 16 is out of range
+    ctx.streams_set_source_index(U, index)
+    ctx.streams_record(T)
+    for t in range(T):
+        ctx.stream_step_dev(ug[t].data_ptr(), ud[t].data_ptr(), S)
+    traj = ctx.trajectories(S, T)  # [S, T, 16]: pose, status, inliers, rc, used_fallback
+    final = ctx.stream_results(S)
+    with pytest.raises(Exception):  # the host-buffer form refuses to run with an index set
+        ctx.stream_step(np.zeros((S, 480, 640), np.uint8), np.zeros((S, 480, 640), np.uint16), S)
+    sample = [0, 127, 128, 200, 255, 256, 383, 384, 450, 511]
+    for s in sample:
+        ovo = OracleVO(Oracle(intr640, odef(warmup_frames=warm)))
+        for t in range(T):
+            ro = ovo.process(seqs[s % U][t][0], seqs[s % U][t][1])
+            assert traj[s, t, 14] == ro["rc"], (s, t)
+            if t >= warm:
+                assert (traj[s, t, 12], traj[s, t, 13]) == (ro["status"], ro["num_inliers"]), (s, t)
+                assert ro["status"] == 1 and traj[s, t, 15] == 0
+            assert np.abs(traj[s, t, :12].reshape(3, 4) - ro["pose"]).max() < 1e-8, (s, t)
+        assert (final[s]["fast_thr"], final[s]["keyframe_changed"], final[s]["num_matches"]) == (ro["fast_thr"], ro["keyframe_changed"], ro["num_matches"]), s
+        ovo.close()
+    first = {}
+    for s in sample:
+        first.setdefault(s % U, s)
+    for s in range(S):
+        ref = first.get(s % U, s % U)  # an oracle-checked stream where one plays this sequence, else the first replica
+        assert np.array_equal(traj[s], traj[ref]), (s, ref)
+        assert np.array_equal(final[s]["cov"], final[ref]["cov"]) and final[s]["fast_thr"] == final[ref]["fast_thr"], s
+        gt = np.linalg.inv(seqs[s % U][warm - 1][2]) @ seqs[s % U][T - 1][2]
+        assert np.abs(traj[s, -1, :12].reshape(3, 4) - gt[:3]).max() < 5e-3, s
+    ctx.close()
