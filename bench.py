@@ -69,6 +69,165 @@ def make_sequence_frames(n_frames: int, seed: int = 0):
     return np.stack([o[0] for o in out]), np.stack([o[1] for o in out]), poses
 
 
+def _render_any_pair(args):
+    seed, size, contrast, invalid = args
+    from slam_amd import synth
+    intr = synth.default_intrinsics(*size)
+    g0, d0, g1, d1, T = synth.make_pair(seed, intr, synth.PlaneScene(contrast=contrast), invalid_frac=invalid)
+    return g0, d0, g1, d1, T[:3]
+
+
+def _render_stream_seq(args):
+    seed, n = args
+    from slam_amd import synth
+    intr = synth.default_intrinsics(640, 480)
+    return [(g, d) for g, d, _ in synth.make_sequence(n, seed=seed, intr=intr, scene=synth.PlaneScene(seed=seed % 4))]
+
+
+LEG_STREAMS, LEG_UNIQUE, LEG_SEQ_T = 512, 16, 6      # configs[2] per GPU: 512 streams replaying 16 sequences of 6 frames
+LEG_BIG_PAIRS = 32                                     # configs[3]: 1280x960, 4 levels, pairs per batch
+LEG_ADV_PAIRS = 256                                    # configs[4]: low texture + 30 % invalid depth
+
+
+def make_leg_inputs():
+    """Synthetic inputs of the configs[2] / [3] / [4] legs (rendered by a pool before anything touches the GPU)."""
+    from concurrent.futures import ProcessPoolExecutor
+    from slam_amd import synth
+    synth.make_texture()
+    workers = int(os.environ.get("RVO_BENCH_WORKERS", "8"))
+    with ProcessPoolExecutor(max_workers=workers) as ex:
+        seqs = list(ex.map(_render_stream_seq, [(900 + u, LEG_SEQ_T) for u in range(LEG_UNIQUE)]))
+        big = list(ex.map(_render_any_pair, [(7000 + i, (1280, 960), 1.0, 0.0) for i in range(LEG_BIG_PAIRS)]))
+        adv = list(ex.map(_render_any_pair, [(40 + i, (640, 480), 0.12, 0.3) for i in range(LEG_ADV_PAIRS)], chunksize=4))
+
+    def stack(pairs):
+        g = np.stack([x for p in pairs for x in (p[0], p[2])])
+        d = np.stack([x for p in pairs for x in (p[1], p[3])])
+        return g, d, np.stack([p[4] for p in pairs])
+    return dict(seqs=seqs, big=stack(big), adv=stack(adv))
+
+
+def path_bytes(W, H, L, K, N):
+    """(B_frame, B_pair, B_step) at K keypoints per frame and N matches per pair."""
+    G = W * H
+    P = sum((W >> l) * (H >> l) for l in range(1, L))
+    b_frame = G + 2 * P + 128 * K + 4 * K
+    return b_frame, 2 * b_frame + 160 * K + N * N / 4, b_frame + 160 * K + N * N / 4
+
+
+def run_pair_leg(name, intr, params, gray, depth, T_gt, thr, dev_index, steps, warmup, log, oracle_pairs):
+    """One FrameMatcher::Match batch per step through the staged pipeline (the configs[1] arrangement) on other inputs:
+    pairs/s with the inputs resident in HBM, result statistics, and a count check of a few pairs against the oracle."""
+    import torch
+    from slam_amd.api import PipelinedFrameMatcher, STATUS_NAMES
+    n_pairs = len(T_gt)
+    dev = torch.device("cuda", dev_index)
+    d_gray = torch.from_numpy(gray).to(dev)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
+    pipe = PipelinedFrameMatcher(intr, n_pairs, params=params, device=dev_index)
+    torch.cuda.synchronize()
+    for _ in range(warmup):
+        pipe.submit(d_gray.data_ptr(), d_depth.data_ptr(), thr)
+    pipe.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.submit(d_gray.data_ptr(), d_depth.data_ptr(), thr)
+    pipe.sync()
+    dt = time.perf_counter() - t0
+    last = pipe.k - 1
+    res = pipe.results(last)
+    ctx = pipe.context_of(last)
+    L = params.num_pyramid_levels
+    kp = [sum(ctx.level_info(int(s), l)["num_keypoints"] for l in range(L)) for s in pipe.slots_of(last)[::max(1, 2 * n_pairs // 16)]]
+    K, N = float(np.mean(kp)), float(np.mean([r["num_matches"] for r in res]))
+    ok = [i for i, r in enumerate(res) if r["status"] == 1]
+    hist = {}
+    for r in res:
+        hist[STATUS_NAMES[r["status"]]] = hist.get(STATUS_NAMES[r["status"]], 0) + 1
+    same = None
+    if oracle_pairs:
+        from oracle.pyoracle import Oracle, default_params as odef
+        orc = Oracle(intr, odef(frame_matcher=True, num_pyramid_levels=L))
+        same = 0
+        for i in range(oracle_pairs):
+            orc.prepare(0, gray[2 * i], depth[2 * i], thr)
+            orc.prepare(1, gray[2 * i + 1], depth[2 * i + 1], thr)
+            ro = orc.match_pair(0, 1)
+            same += int((ro["status"], ro["num_matches"], ro["num_inliers"]) == (res[i]["status"], res[i]["num_matches"], res[i]["num_inliers"])
+                        and float(np.abs(ro["pose"] - res[i]["pose"]).max()) < 1e-8)
+        orc.close()
+    pipe.close()
+    _, b_pair, _ = path_bytes(intr["width"], intr["height"], L, K, N)
+    rate = n_pairs * steps / dt
+    log(f"{name} leg done")
+    return dict(value=rate, unit="frame-pairs/s", pairs_per_batch=n_pairs, steps=steps, warmup=warmup, ms_per_step=dt / steps * 1e3,
+                mean_kp_per_frame=K, mean_matches=N, mean_inliers=float(np.mean([r["num_inliers"] for r in res])),
+                status_histogram=hist,
+                max_abs_pose_err_vs_truth=float(max(np.abs(res[i]["pose"] - T_gt[i]).max() for i in ok)) if ok else None,
+                bytes_per_pair=b_pair, roofline_path_frac=rate * b_pair / HBM_PEAK,
+                oracle_check=f"{same}/{oracle_pairs} pairs with the oracle's status, match and inlier counts and pose (1e-8)" if oracle_pairs else None,
+                oracle_pairs_identical=same, oracle_pairs_checked=oracle_pairs)
+
+
+def run_stream_leg(seqs, dev_index, steps, warmup, log, oracle_streams=2, oracle_steps=10):
+    """configs[2] per GPU: LEG_STREAMS lock-step streams through rvo_stream_step_dev (RGBDVO::ProcessFrame, vo.cpp:55-165)
+    on ONE context (the library cuts a step into four groups of 128), images resident in HBM once per distinct sequence
+    (rvo_streams_set_source_index), trajectories recorded on the device, nothing synchronised between the steps."""
+    import torch
+    from slam_amd import synth
+    from slam_amd.api import Context, default_params
+    S, U, T = LEG_STREAMS, len(seqs), len(seqs[0])
+    intr = synth.default_intrinsics(640, 480)
+    dev = torch.device("cuda", dev_index)
+    ug = torch.from_numpy(np.stack([np.stack([seqs[u][t][0] for u in range(U)]) for t in range(T)])).to(dev)  # [T, U, H, W]
+    ud = torch.from_numpy(np.stack([np.stack([seqs[u][t][1] for u in range(U)]) for t in range(T)]).view(np.int16)).to(dev)
+    p = default_params(warmup_frames=1)  # the reference discards 99 frames first (vo.cpp:58-69); the synthetic streams start at once
+    ctx = Context(intr, p, max_frames=3 * S, max_pairs=S, device=dev_index)
+    ctx.streams_reset(S)
+    ctx.streams_set_source_index(U, np.arange(S) % U)
+    ctx.streams_record(warmup + steps)
+    order = list(range(T)) + list(range(T - 2, 0, -1))  # forward and back: consecutive frames always overlap
+    torch.cuda.synchronize()
+    for k in range(warmup):
+        t = order[k % len(order)]
+        ctx.stream_step_dev(ug[t].data_ptr(), ud[t].data_ptr(), S)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for k in range(warmup, warmup + steps):
+        t = order[k % len(order)]
+        ctx.stream_step_dev(ug[t].data_ptr(), ud[t].data_ptr(), S)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    traj = ctx.trajectories(S, warmup + steps)  # [S, steps, 16]: pose 3x4, status, inliers, rc, used_fallback
+    final = ctx.stream_results(S)
+    kp = [sum(ctx.level_info(3 * s + j, l)["num_keypoints"] for l in range(3)) for s in range(0, S, 64) for j in range(3)]
+    K, N = float(np.mean(kp)), float(np.mean([r["num_matches"] for r in final]))
+    replicas_equal = all(np.array_equal(traj[s], traj[s % U]) for s in range(U, S))
+    from oracle.pyoracle import Oracle, OracleVO, default_params as odef
+    same, total = 0, 0
+    for s in range(oracle_streams):
+        ovo = OracleVO(Oracle(intr, odef(warmup_frames=1)))
+        for k in range(min(oracle_steps, warmup + steps)):
+            t = order[k % len(order)]
+            ro = ovo.process(seqs[s % U][t][0], seqs[s % U][t][1])
+            total += 1
+            same += int(traj[s, k, 14] == ro["rc"] and (k == 0 or (traj[s, k, 12], traj[s, k, 13]) == (ro["status"], ro["num_inliers"]))
+                        and float(np.abs(traj[s, k, :12].reshape(3, 4) - ro["pose"]).max()) < 1e-8)
+        ovo.close()
+    ctx.close()
+    _, _, b_step = path_bytes(640, 480, 3, K, N)
+    rate = S * steps / dt
+    log("configs2 leg done")
+    return dict(value=rate, unit="stream-frames/s", streams=S, contexts=1, unique_sequences=U, steps=steps, warmup=warmup,
+                ms_per_step=dt / steps * 1e3, mean_kp_per_frame=K, mean_matches=N,
+                mean_inliers=float(np.mean([r["num_inliers"] for r in final])),
+                estimates_ok=int((traj[:, 1:, 12] == 1).sum()), estimates=S * (warmup + steps - 1),
+                fallbacks=int(traj[:, :, 15].sum()), replicas_bit_equal=bool(replicas_equal),
+                bytes_per_step=b_step, roofline_path_frac=rate * b_step / HBM_PEAK,
+                oracle_check=f"{same}/{total} stream steps (streams 0..{oracle_streams - 1}, first {oracle_steps} steps) with OracleVO's rc, status, inlier count and pose (1e-8)",
+                oracle_steps_identical=same, oracle_steps_checked=total)
+
+
 def algorithmic_bytes(geom: dict, stats: dict) -> dict:
     """Algorithmic HBM bytes per LAUNCH of each kernel kind (definitions: DESIGN.md section 5)."""
     W, H, L = geom["W"], geom["H"], geom["levels"]
@@ -101,6 +260,7 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=3, help="passes over those pairs (about 10 s of CPU work in all)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--seq-frames", type=int, default=300, help="frames of the configs[0] sequence timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the configs[2] / configs[3] / configs[4] legs (rank 0, N=1 only)")
     ap.add_argument("--prewarm", type=float, default=float(os.environ.get("RVO_BENCH_PREWARM_S", "1.0")),
                     help="seconds of untimed work before the warm-up steps (clocks of an idle box)")
     a = ap.parse_args()
@@ -131,6 +291,7 @@ def main():
     if world == 1 and not a.no_cpu and a.seq_frames > 0:
         seq = make_sequence_frames(a.seq_frames)
 
+    legs_in = make_leg_inputs() if (world == 1 and not a.no_legs) else None
     log("inputs made")
     import torch
     import torch.distributed as dist
@@ -411,6 +572,26 @@ def main():
                                     "latency-bound, the GPU is built for many streams (configs[2])",
                            frames_identical_to_gpu=same_seq, max_abs_pose_diff_vs_gpu=dpose,
                            drift_after_all_frames_m=terr)
+        legs = {}
+        if legs_in is not None:
+            # BASELINE.json configs[2..4] as driver-run numbers, after the timed region, on the same GPU;
+            # the configs[1] contexts are closed first (their work areas are not needed any more)
+            from slam_amd.api import default_params as dparams
+            for c in ctxs:
+                c.close()
+            ctxs = []
+            legs["configs2_per_gpu"] = run_stream_leg(legs_in["seqs"], dev_index, steps=60, warmup=6, log=log)
+            g3, d3, T3 = legs_in["big"]
+            legs["configs3"] = run_pair_leg("configs3", synth.default_intrinsics(1280, 960), dparams(frame_matcher=True, num_pyramid_levels=4),
+                                            g3, d3, T3, thr, dev_index, steps=40, warmup=5, log=log, oracle_pairs=2 if not a.no_cpu else 0)
+            legs["configs3"]["workload"] = "configs[3]: 1280x960, 4 pyramid levels, 32 independent pairs per batch, device-resident inputs"
+            g4, d4, T4 = legs_in["adv"]
+            legs["configs4"] = run_pair_leg("configs4", intr, dparams(frame_matcher=True), g4, d4, T4, 5, dev_index, steps=40, warmup=5,
+                                            log=log, oracle_pairs=8 if not a.no_cpu else 0)
+            legs["configs4"]["workload"] = ("configs[4]: adversarial 640x480 pairs (texture contrast 0.12 = about 5 grey levels, 30 % of the depth "
+                                            "invalid in blobs and salt noise, FAST threshold at its floor 5), 256 pairs per batch")
+            legs["configs2_per_gpu"]["workload"] = ("configs[2] per-GPU shard: 512 lock-step 640x480 streams through rvo_stream_step_dev on one "
+                                                    "context, 16 distinct sequences replayed, device-resident inputs")
         line = dict(metric="frame-pairs/sec (whole node) at 640x480", value=value, unit="frame-pairs/s",
                     n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8/int32/f64", data="synthetic",
@@ -427,7 +608,8 @@ def main():
                                  "(that instrumentation costs about 7 %); the timed region brackets only the dominant kernel", stats=stats,
                     check=dict(pairs_success=ok, max_abs_pose_err_vs_truth=float(err)),
                     gather_ms=gather_ms, gather_total_ms=gather_total_ms, gather_backend=gather_backend, gather_ranks=gather_ranks,
-                    gather_hung=verdict["gather_hung"], gather_ok=verdict["gather_ok"], gather_over_rccl=verdict["gather_over_rccl"])
+                    gather_hung=verdict["gather_hung"], gather_ok=verdict["gather_ok"], gather_over_rccl=verdict["gather_over_rccl"],
+                    **legs)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         # a hung collective, or a gather that bypassed RCCL although every rank has a GPU of its own, must not look green:
