@@ -475,15 +475,23 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   // four-pixel groups: group j of score row sy covers tile x = 4j..4j+3 (score column sx sits at tile x = sx + 3 + shl)
   const int jlo = (shl + 3) >> 2, ngr = ((shl + sw + 2) >> 2) - jlo + 1;
   const int inv_ngr = (int)kInv16.v[ngr];  // ngr <= 64; t / ngr == (t * inv_ngr) >> 16 for t <= 256
-  const int nseg = (256 * inv_ngr) >> 16, rows_per = ((sh + nseg - 1) * (int)kInv16.v[nseg]) >> 16;  // 256 / ngr, ceil(sh / nseg)
-  const bool strips = rows_per <= 8;      // column strips (below); otherwise the generic walker
+  const int nseg = (256 * inv_ngr) >> 16;  // 256 / ngr
+  // Column strips (below) when the tile's columns are dword-aligned with the image's (shl == 0: cells that start on a
+  // multiple of 4): four-pixel groups that start at score column 0 (tile x = 4j + 3), so the sw columns take
+  // ceil(sw / 4) groups -- 21 for the default 82, which leaves 12 strips of 7 rows to the 256 threads (84 x 84 pixel tests for
+  // 82 x 82; dword-aligned groups needed 22 x 11 strips of 8 rows = 88 x 88).  Other shapes: the generic walker.
+  const int ngs = (sw + 3) >> 2;
+  const int inv_ngs = (int)kInv16.v[ngs];
+  const int nsegs = (256 * inv_ngs) >> 16, rows_per_s = ((sh + nsegs - 1) * (int)kInv16.v[nsegs]) >> 16;  // 256 / ngs, ceil(sh / nsegs)
+  constexpr int NR = 7;  // rows the strip code is unrolled for (more would cost registers: 2 per row); row k of a strip sits at bit k + 8 - NR of its byte
+  const bool strips = shl == 0 && rows_per_s <= NR;
   const int sylo = max(0, 4 - cy0);       // first score row with gy >= 3
   {
     // 4 horizontally adjacent pixels per iteration: aligned LDS dwords (centre, left, right, 3 rows up, 3 rows down)
     // feed two packed-u16 evaluations (even / odd bytes).  Group j of score row sy covers tile x = 4j..4j+3.
-    const int seg = (tid * inv_ngr) >> 16, sj = jlo + tid - seg * ngr;  // tid / ngr, jlo + tid % ngr
     const int q = nseg, rr = 256 - nseg * ngr;
-    const int gsy0 = seg, gj0 = sj;
+    // the walker's first group (recomputed where it is used: nothing of it stays live across the strips)
+    auto walker_start = [&](int* sy_, int* j_) { const int seg = (tid * inv_ngr) >> 16; *sy_ = seg; *j_ = jlo + tid - seg * ngr; };
     const int txlo = max(3, 7 - cx0) + shl, txhi = min(sw + 2, G.w - cx0) + shl;  // fast9Detect loop bounds, feature.cpp:3042-3043
     const uint32_t cd1 = 0x7FFFu - (uint32_t)min(b, 255);
     const uint32_t cd2 = cd1 | (cd1 << 16);
@@ -492,48 +500,61 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     // and "3 down" row of three score rows (static register indexing, no index walkers).  The verdicts of a strip are
     // shifted into two 32-bit masks (bright, dark): pixel p of row k at bit 8p + k.
     // Other shapes use the generic walker below (64-bit masks, 4 bits per visited group).
-    int r0 = 0;  // first score row of this thread's strip (strips only)
     uint32_t sb = 0, sdk = 0;             // strips: bright / dark masks
     unsigned long long gb64 = 0, gd64 = 0;  // generic walker: bright / dark masks
+    const int segs = (tid * inv_ngs) >> 16, sjs = tid - segs * ngs;  // strips: tid / ngs, tid % ngs
     if (strips) {
       const int syhi = min(sh - 1, G.h - 3 - cy0);  // rows sylo..syhi have 3 <= gy <= h-4
-      r0 = max(seg * rows_per, sylo);
-      const int r1 = min(min(seg * rows_per + rows_per, sh) - 1, syhi);
-      const uint32_t vm = (0xFu << min(max(txlo - 4 * sj, 0), 4)) & (0xFu >> min(max(4 * sj + 3 - txhi, 0), 4)) & 0xFu;
-      if (seg < nseg && r0 <= r1 && vm) {
-        const uint8_t* col = s_tile + r0 * TP + 4 * sj;  // tile row r0 = "3 up" of score row r0
+      const int r0 = max(segs * rows_per_s, sylo);  // first score row of this thread's strip
+      const int r1 = min(min(segs * rows_per_s + rows_per_s, sh) - 1, syhi);
+      const int sxlo = max(0, 4 - cx0), sxhi = min(sw - 1, G.w - 3 - cx0);  // fast9Detect loop bounds in score columns
+      const uint32_t vm = (0xFu << min(max(sxlo - 4 * sjs, 0), 4)) & (0xFu >> min(max(4 * sjs + 3 - sxhi, 0), 4)) & 0xFu;
+      if (segs < nsegs && r0 <= r1 && vm) {
+        const uint8_t* col = s_tile + r0 * TP + 4 * sjs;  // tile row r0 = "3 up" of score row r0; dword D0 of the group
         const int nrows = r1 - r0 + 1;
-        uint32_t Ce[14], Co[14];
+        // The four pixels of group j are tile bytes 4j+3 .. 4j+6 = D0.b3 D1.b0 D1.b1 D1.b2 of the row's dwords D0 D1 D2 at
+        // 4j; their west neighbours (x-3) are D0.b0..b3, their east neighbours (x+3) D1.b2 D1.b3 D2.b0 D2.b1.  Rows past
+        // the strip read other LDS rows of this workgroup and are masked off below.
+        {
+          uint32_t Ce[NR + 6], Co[NR + 6];
+          // sched_barriers keep the compiler from issuing every LDS read of the strip first (one register per read: 100
+          // VGPRs instead of 48, a third of the occupancy): four rows of centre dwords at a time, and in the loop below
+          // the next row's three dwords while the current row is evaluated
 #pragma unroll
-        for (int k = 0; k < 14; k++) {
-          const uint32_t C = (k < nrows + 6) ? *reinterpret_cast<const uint32_t*>(col + k * TP) : 0u;
-          Ce[k] = C & 0x00FF00FFu;
-          Co[k] = __builtin_amdgcn_perm(0u, C, 0x0C030C01u);
-        }
+          for (int k0 = 0; k0 < NR + 6; k0 += 4) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) {  // rows past the strip read other LDS rows of this workgroup and are masked off below
-          const uint8_t* row = col + (k + 3) * TP;
-          const uint32_t C = *reinterpret_cast<const uint32_t*>(row);
-          const uint32_t Lw = *reinterpret_cast<const uint32_t*>(row - 4);
-          const uint32_t R = *reinterpret_cast<const uint32_t*>(row + 4);
-          // west = tile x-3 of the four pixels = Lw.b1 Lw.b2 Lw.b3 C.b0; east = x+3 = C.b3 R.b0 R.b1 R.b2
-          const uint32_t We = __builtin_amdgcn_perm(0u, Lw, 0x0C030C01u), Wo = __builtin_amdgcn_perm(C, Lw, 0x0C040C02u);
-          const uint32_t Ee = __builtin_amdgcn_perm(R, C, 0x0C050C03u), Eo = R & 0x00FF00FFu;
-          uint32_t tbe, tde, tbo, tdo;
-          compass2f(Ce[k + 3], Ce[k + 6], Ce[k], Ee, We, cd2, &tbe, &tde);
-          compass2f(Co[k + 3], Co[k + 6], Co[k], Eo, Wo, cd2, &tbo, &tdo);
-          // the verdicts are bit 15 of the halves = bit 7 of bytes 1 and 3: one v_perm gathers the four bytes (pixel p ->
-          // byte p), and shifting the mask right once per row leaves row k at bit k of every byte
-          sb = (sb >> 1) | (__builtin_amdgcn_perm(tbo, tbe, 0x07030501u) & 0x80808080u);
-          sdk = (sdk >> 1) | (__builtin_amdgcn_perm(tdo, tde, 0x07030501u) & 0x80808080u);
+            for (int k = k0; k < k0 + 4 && k < NR + 6; k++) {
+              const uint32_t D0 = *reinterpret_cast<const uint32_t*>(col + k * TP);
+              const uint32_t D1 = *reinterpret_cast<const uint32_t*>(col + k * TP + 4);
+              Ce[k] = __builtin_amdgcn_perm(D1, D0, 0x0C050C03u);
+              Co[k] = D1 & 0x00FF00FFu;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int k = 0; k < NR; k++) {
+            const uint8_t* row = col + (k + 3) * TP;
+            const uint32_t D0 = *reinterpret_cast<const uint32_t*>(row), D1 = *reinterpret_cast<const uint32_t*>(row + 4), D2 = *reinterpret_cast<const uint32_t*>(row + 8);
+            const uint32_t We = D0 & 0x00FF00FFu, Wo = __builtin_amdgcn_perm(0u, D0, 0x0C030C01u);
+            const uint32_t Ee = __builtin_amdgcn_perm(D2, D1, 0x0C040C02u), Eo = __builtin_amdgcn_perm(D2, D1, 0x0C050C03u);
+            uint32_t tbe, tde, tbo, tdo;
+            compass2f(Ce[k + 3], Ce[k + 6], Ce[k], Ee, We, cd2, &tbe, &tde);
+            compass2f(Co[k + 3], Co[k + 6], Co[k], Eo, Wo, cd2, &tbo, &tdo);
+            // the verdicts are bit 15 of the halves = bit 7 of bytes 1 and 3: one v_perm gathers the four bytes (pixel p ->
+            // byte p), and shifting the mask right once per row leaves row k at bit k + 8 - NR of every byte
+            sb = (sb >> 1) | (__builtin_amdgcn_perm(tbo, tbe, 0x07030501u) & 0x80808080u);
+            sdk = (sdk >> 1) | (__builtin_amdgcn_perm(tdo, tde, 0x07030501u) & 0x80808080u);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const uint32_t keep = ((((1u << nrows) - 1u) << (8 - NR)) * 0x01010101u) &
+                                (((vm & 1u) ? 0x000000FFu : 0u) | ((vm & 2u) ? 0x0000FF00u : 0u) | ((vm & 4u) ? 0x00FF0000u : 0u) |
+                                 ((vm & 8u) ? 0xFF000000u : 0u));
+          sb &= keep; sdk &= keep;
         }
-        const uint32_t keep = (((1u << nrows) - 1u) * 0x01010101u) &
-                              (((vm & 1u) ? 0x000000FFu : 0u) | ((vm & 2u) ? 0x0000FF00u : 0u) | ((vm & 4u) ? 0x00FF0000u : 0u) |
-                               ((vm & 8u) ? 0xFF000000u : 0u));
-        sb &= keep; sdk &= keep;
       }
     }
-    int sy = gsy0, j = gj0;
+    int sy = 0, j = 0;
+    if (!strips) walker_start(&sy, &j);
     for (int k = 0; !strips && sy < sh; k++) {
       const int gy = cy0 + sy - 1;
       if (gy >= 3 && gy <= G.h - 4) {
@@ -590,7 +611,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
       drain(sdk, posd, -1);
     }
     if (fits && !strips) {
-      sy = gsy0; j = gj0;
+      walker_start(&sy, &j);
       for (int k = 0; k < 16 && ((gb64 | gd64) >> (4 * k)); k++) {
         uint32_t bits = (uint32_t)(gb64 >> (4 * k)) & 0xFu;
         while (bits) {
@@ -623,9 +644,9 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     int sy = v >> 8, sx = v & 255;
     if (strips) {  // entry = (producer thread << 5 | bit of its strip mask): pixel p of row k at bit 8p + k
       const int t = v >> 5, qb = v & 31;
-      const int seg = (t * inv_ngr) >> 16;
-      sy = max(seg * rows_per, sylo) + (qb & 7);
-      sx = 4 * (jlo + t - seg * ngr) + (qb >> 3) - 3 - shl;
+      const int seg = (t * inv_ngs) >> 16;
+      sy = max(seg * rows_per_s, sylo) + (qb & 7) - (8 - NR);
+      sx = 4 * (t - seg * ngs) + (qb >> 3);
       s_cand[qi] = (uint16_t)((sy << 8) | sx);  // for the NMS pass (same thread, same entry)
     }
     const int A = fast9_A_pol(s_tile + (sy + 3) * TP + (sx + 3 + shl), TP, bright ? 1 : -1);
