@@ -366,6 +366,27 @@ __device__ int g_fast_stop;  // ablation: return after phase i (99 = run everyth
 #define FAST_PHASE(i) do { } while (0)
 #endif
 
+// descriptor tap m (0..9) of lane sub (0..7) of a keypoint's 8-lane group in k_fast_grid: descriptor dwords sub and
+// 8 + sub (taps 4 sub.., 32 + 4 sub..) and the two bytes 64 + 2 sub, 65 + 2 sub
+__host__ __device__ constexpr int desc_tap_of_lane(int sub, int m) {
+  return m < 4 ? 4 * sub + m : m < 8 ? 32 + 4 * sub + (m - 4) : 64 + 2 * sub + (m - 8);
+}
+// the taps' byte offsets from the keypoint in a tile of pitch TP, two int16 per word
+template <int TP>
+struct DescTaps {
+  uint32_t w[8][5];
+  constexpr DescTaps() : w{} {
+    for (int sub = 0; sub < 8; sub++)
+      for (int q = 0; q < 5; q++) {
+        const int t0 = desc_tap_of_lane(sub, 2 * q), t1 = desc_tap_of_lane(sub, 2 * q + 1);
+        const int o0 = (t0 / 9 - 4) * TP + (t0 % 9 - 4), o1 = (t1 / 9 - 4) * TP + (t1 % 9 - 4);
+        w[sub][q] = ((uint32_t)o0 & 0xFFFFu) | ((uint32_t)o1 << 16);
+      }
+  }
+};
+template <int TP>
+__device__ const DescTaps<TP> kDescTaps{};
+
 struct FastLds {  // byte offsets into dynamic LDS, computed on the host (all multiples of 4)
   int tile_pitch, score_pitch;
   int cand_cap;  // phase-A candidate queue entries (u16)
@@ -737,33 +758,56 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   {
     static_assert(RVO_DESC_LEN == 80, "lane -> tap assignment below");
     const int sub = tid & 7, grp = tid >> 3;
+    // tap offsets of this lane relative to the keypoint's tile byte: from a table in constant memory when the pitch is a
+    // compile-time constant (two 16-bit offsets per word; computing t / 9, t % 9 for ten taps cost 70 instructions)
     int toff[10];
+    if (TPC) {
 #pragma unroll
-    for (int m = 0; m < 10; m++) {
-      const int t = m < 4 ? 4 * sub + m : m < 8 ? 32 + 4 * sub + (m - 4) : 64 + 2 * sub + (m - 8);
-      toff[m] = (t / 9 - 4) * TP + (t % 9 - 4);
+      for (int q = 0; q < 5; q++) {
+        const uint32_t w = kDescTaps<TPC ? TPC : 4>.w[sub][q];
+        toff[2 * q] = (int)(short)(w & 0xFFFFu);
+        toff[2 * q + 1] = (int)w >> 16;
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 10; m++) {
+        const int t = desc_tap_of_lane(sub, m);
+        toff[m] = (t / 9 - 4) * TP + (t % 9 - 4);
+      }
     }
     for (int i = grp; i < keep; i += 32) {
       const uint32_t k = s_list[i];
       const uint8_t* c = s_tile + (kp_y(k) - cy0 + 4) * TP + (kp_x(k) - cx0 + 4 + shl);
-      int v[10];
+      // the ten taps as five u16 pairs, each value in the HIGH byte of its half (v << 8): the saturating packed adds
+      // then clamp at 255 (0xFFFF >> 8) and at 0 exactly as Descriptor::Normalized's _mm_adds_epu8 / _mm_subs_epu8 do,
+      // one instruction per two taps and direction
+      us2_t P[5];
 #pragma unroll
-      for (int m = 0; m < 10; m++) v[m] = (int)c[toff[m]];
+      for (int q = 0; q < 5; q++)
+        P[q] = __builtin_bit_cast(us2_t, __builtin_amdgcn_perm((uint32_t)c[toff[2 * q + 1]], (uint32_t)c[toff[2 * q]], 0x040C000Cu));
 #pragma unroll
       for (int pass = 0; pass < 2; pass++) {
-        int sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) + (v[8] + v[9]);
-        sum += __builtin_amdgcn_update_dpp(0, sum, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-        sum += __builtin_amdgcn_update_dpp(0, sum, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-        sum += __builtin_amdgcn_update_dpp(0, sum, 0x141, 0xF, 0xF, true);  // row_half_mirror: the 8 lanes of the group
-        const int mean = sum / RVO_DESC_LEN;
+        // the lane's tap sum: v_dot4 over the two value bytes of every pair (the low bytes are not always zero: a half that
+        // saturated holds 0xFFFF), on two accumulators (a dependent dot chain pays wait states)
+        auto hw = [](us2_t x) { return __builtin_bit_cast(uint32_t, x); };
+        const uint32_t sa = __builtin_amdgcn_udot4(hw(P[4]), 0x01000100u, __builtin_amdgcn_udot4(hw(P[2]), 0x01000100u, __builtin_amdgcn_udot4(hw(P[0]), 0x01000100u, 0u, false), false), false);
+        const uint32_t sb2 = __builtin_amdgcn_udot4(hw(P[3]), 0x01000100u, __builtin_amdgcn_udot4(hw(P[1]), 0x01000100u, 0u, false), false);
+        uint32_t sum = sa + sb2;
+        sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x141, 0xF, 0xF, true);  // row_half_mirror: the 8 lanes of the group
+        const int mean = (int)(sum / (uint32_t)RVO_DESC_LEN);
         const int o = 128 - mean;  // mean < 128: add and clamp at 255; mean > 128: subtract and clamp at 0
+        const us2_t up = __builtin_bit_cast(us2_t, __builtin_amdgcn_perm(0u, (uint32_t)max(o, 0), 0x000C000Cu));
+        const us2_t dn = __builtin_bit_cast(us2_t, __builtin_amdgcn_perm(0u, (uint32_t)max(-o, 0), 0x000C000Cu));
 #pragma unroll
-        for (int m = 0; m < 10; m++) v[m] = min(255, max(0, v[m] + o));
+        for (int q = 0; q < 5; q++) P[q] = __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(P[q], up), dn);
       }
       uint8_t* dsc = fb.bk_desc + (bslot + i) * RVO_DESC_LEN;
-      reinterpret_cast<uint32_t*>(dsc)[sub] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
-      reinterpret_cast<uint32_t*>(dsc)[8 + sub] = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
-      reinterpret_cast<uint16_t*>(dsc)[32 + sub] = (uint16_t)(v[8] | (v[9] << 8));
+      auto hb = [](us2_t x) { return __builtin_bit_cast(uint32_t, x); };
+      reinterpret_cast<uint32_t*>(dsc)[sub] = __builtin_amdgcn_perm(hb(P[1]), hb(P[0]), 0x07050301u);
+      reinterpret_cast<uint32_t*>(dsc)[8 + sub] = __builtin_amdgcn_perm(hb(P[3]), hb(P[2]), 0x07050301u);
+      reinterpret_cast<uint16_t*>(dsc)[32 + sub] = (uint16_t)__builtin_amdgcn_perm(0u, hb(P[4]), 0x0C0C0301u);
     }
   }
   FAST_PHASE(6);  // lists + descriptors (thread 0's share)
