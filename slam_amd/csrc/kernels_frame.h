@@ -449,17 +449,19 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     const int r0s = (tid * inv_t16) >> 16, c = tid - r0s * t16;  // tid / t16, tid % t16 (exact for tid <= 256)
     const int gx = gx0 + 16 * c;
     const int d0 = 4 * c - sd;
-    const bool colok = gx >= 0 && gx < G.stride;
+    // Loads are never predicated: row and column are clamped into the image instead (32-bit offsets from the uniform
+    // image pointer).  Tile bytes outside the image then hold copies of edge pixels; every test that would read them is
+    // masked by the image bounds (fast9Detect's loop bounds; keypoints whose 9x9 window leaves the image are dropped by
+    // k_build_keypoints' border test, so their descriptor rows are never used).
+    const int gxc = min(max(gx, 0), G.stride - 16);
     const bool w0 = d0 >= 0 && d0 < tdw, w1 = d0 + 1 >= 0 && d0 + 1 < tdw, w2 = d0 + 2 >= 0 && d0 + 2 < tdw, w3 = d0 + 3 >= 0 && d0 + 3 < tdw;
-    const uint8_t* __restrict__ src = img + gx;
     if (r0s < rpp) {
       for (int r = r0s; r < trows; r += 3 * rpp) {
         uint4 v[3];
 #pragma unroll
         for (int u = 0; u < 3; u++) {
-          const int gy = gy0 + r + u * rpp;
-          v[u] = make_uint4(0u, 0u, 0u, 0u);
-          if (colok && r + u * rpp < trows && gy >= 0 && gy < G.h) v[u] = gload_u4(src + (size_t)gy * G.stride);
+          const int gy = min(max(gy0 + r + u * rpp, 0), G.h - 1);
+          v[u] = gload_u4(img + (uint32_t)(gy * G.stride + gxc));
         }
 #pragma unroll
         for (int u = 0; u < 3; u++) {
