@@ -185,6 +185,7 @@ def run_stream_leg(seqs, dev_index, steps, warmup, log, oracle_streams=2, oracle
     ctx = Context(intr, p, max_frames=3 * S, max_pairs=S, device=dev_index)
     ctx.streams_reset(S)
     ctx.streams_set_source_index(U, np.arange(S) % U)
+    ctx.streams_depth_in_place(True)  # every frame's depth image stays resident for the whole leg
     ctx.streams_record(warmup + steps)
     order = list(range(T)) + list(range(T - 2, 0, -1))  # forward and back: consecutive frames always overlap
     torch.cuda.synchronize()

@@ -222,6 +222,14 @@ int rvo_get_stream_results(rvo_ctx* ctx, int n_streams, rvo_stream_result* out);
  * The step copies the images into the streams' frame slots anyway, so the index costs nothing.  index = NULL or
  * n_sources <= 0 clears it; rvo_streams_reset clears it too.  The host-buffer step forms refuse to run with an index. */
 int rvo_streams_set_source_index(rvo_ctx* ctx, int n_sources, const int32_t* index /* [n_streams] */);
+/* No counterpart in the reference (RGBDVO::ProcessFrame copies every depth image, vo.cpp:83-87 + Depth::SetDepth
+ * depth.cpp:42-46): on != 0 makes rvo_stream_step_dev read the depth images where the caller put them instead of copying
+ * them into the frame slots (614 KB of the 921 KB a 640x480 frame brings; only the few thousand pixels under keypoints and
+ * refined matches of the CURRENT frame are ever read, and never after the step).  The caller then keeps depth_dev untouched
+ * until the step has completed (rvo_sync, or a synchronising read of its results), and a stream's frame slots are no longer
+ * valid targets for rvo_match_pairs.  The gray images are always copied (a frame is reference / previous frame of later
+ * steps).  Off after rvo_create and after every rvo_streams_reset; the host-buffer step forms always copy. */
+int rvo_streams_depth_in_place(rvo_ctx* ctx, int on);
 
 /* Frame slots stream `stream` currently holds: out[3] = reference, previous, current frame
  * (ref_frame_/prev_frame_/curr_frame_ of rgbdvo/vo.hpp:67-69) -- lets the facade resolve match indices to keypoints. */

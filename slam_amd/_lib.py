@@ -53,7 +53,7 @@ SYMBOLS = [
     "rvo_get_level_info", "rvo_get_level_image", "rvo_get_grid_keypoints", "rvo_get_keypoints",
     "rvo_stream_step_host_async", "rvo_wait_upload", "rvo_host_alloc", "rvo_host_free", "rvo_get_descriptors", "rvo_get_matches", "rvo_get_match_tracks", "rvo_get_keypoint_tracks", "rvo_reset_tracks", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_select", "rvo_profile_read",
     "rvo_selftest_stdalgo", "rvo_bgr_to_gray_dev", "rvo_depth_to_point_cloud_dev", "rvo_get_pair_information", "rvo_get_pair_information_noalloc", "rvo_set_pair_chunks", "rvo_wait_peer",
-    "rvo_streams_record", "rvo_streams_set_source_index", "rvo_trajectories_dev", "rvo_get_trajectories",
+    "rvo_streams_record", "rvo_streams_set_source_index", "rvo_streams_depth_in_place", "rvo_trajectories_dev", "rvo_get_trajectories",
     "rvo_set_pipeline", "rvo_get_batch_results", "rvo_comm_get_unique_id", "rvo_comm_create", "rvo_comm_destroy", "rvo_gather_trajectories",
 ]
 TRAJ_DOUBLES = 16   # RVO_TRAJ_DOUBLES
@@ -120,6 +120,7 @@ def load():
     L.rvo_get_pair_results.argtypes = [vp, ip, vp]
     L.rvo_initial_rotation.argtypes = [vp, ip, vp, vp, vp]
     L.rvo_streams_reset.argtypes = [vp, ip]
+    L.rvo_streams_depth_in_place.argtypes = [vp, ip]
     L.rvo_stream_step.argtypes = [vp, ip, vp, vp, vp]
     L.rvo_stream_step_dev.argtypes = [vp, ip, vp, vp]
     L.rvo_get_stream_results.argtypes = [vp, ip, vp]

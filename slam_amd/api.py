@@ -281,6 +281,10 @@ class Context:
             index = _i32(index)
             self._chk(self.L.rvo_streams_set_source_index(self.h, n_sources, _ptr(index)))
 
+    def streams_depth_in_place(self, on: bool = True):
+        """rvo_streams_depth_in_place: stream_step_dev reads the depth images where they lie (keep them until the step is done)."""
+        self._chk(self.L.rvo_streams_depth_in_place(self.h, 1 if on else 0))
+
     def stream_results(self, n_streams):
         out = (StreamResult * n_streams)()
         self._chk(self.L.rvo_get_stream_results(self.h, n_streams, out))

@@ -384,11 +384,30 @@ __host__ __device__ inline int match_lds_bytes(int cap) { return cap * 16 + matc
 #ifndef MATCH_MIN_WAVES
 #define MATCH_MIN_WAVES 1
 #endif
+// A level whose keypoint capacity exceeds MATCH_PART_REFS is matched by several workgroups (parts), each taking every
+// nparts-th group of MATCH_WAVES reference keypoints against ALL targets of the level: the one workgroup of level 0 (1200
+// slots) was the longest serial piece of a pair's chain (0.18 ms alone).  A part's per-reference bests are complete; its
+// per-target bests cover its references only, so the parts write both to global memory and k_match_finish takes the
+// minimum over the parts (the keys are (score << 16 | index): the minimum is the reference's first-minimum rule whatever the
+// order) and emits the mutual matches.  Levels with one part finish inside k_match as before.
+#ifndef MATCH_PART_REFS
+#define MATCH_PART_REFS 320
+#endif
+#define MATCH_PARTS_MAX 8
+__host__ __device__ inline int match_parts(int kp_cap) { return min(MATCH_PARTS_MAX, max(1, (kp_cap + MATCH_PART_REFS - 1) / MATCH_PART_REFS)); }
+__host__ __device__ inline int match_grid_x(const FrameGeom& g) {
+  int n = 0;
+  for (int l = 0; l < g.levels; l++) n += match_parts(g.lv[l].kp_cap);
+  return n;
+}
 __global__ __launch_bounds__(MATCH_THREADS, MATCH_MIN_WAVES) void k_match(FrameBufs fb, FrameGeom g, PairBufs pb, CamParams cam, EstParams ep) {
   RVO_OCC_SCOPE(6, 1);
   extern __shared__ __align__(16) uint8_t lds[];
-  const int lvl = blockIdx.x, pair = blockIdx.y + pb.pair0, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int pair = blockIdx.y + pb.pair0, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (!pb.active[pair]) return;
+  int lvl = 0, part = blockIdx.x, nparts = match_parts(g.lv[0].kp_cap);  // blockIdx.x = the parts of level 0, then level 1, ...
+  while (part >= nparts) { part -= nparts; lvl++; nparts = match_parts(g.lv[lvl].kp_cap); }
+  const int gw = part * MATCH_WAVES + wid, TW = nparts * MATCH_WAVES;  // this wave among the level's waves
   const LevelGeom G = g.lv[lvl];
   const int cap = g.lv[0].kp_cap;
   float2* s_tuv = reinterpret_cast<float2*>(lds);
@@ -449,12 +468,12 @@ __global__ __launch_bounds__(MATCH_THREADS, MATCH_MIN_WAVES) void k_match(FrameB
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), j);
     return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
   };
-  // wave `wid` owns the reference keypoints wid, wid+16, ...; 64 of them are projected at a time, one per lane.  Lanes
+  // wave gw of the level's TW waves owns the reference keypoints gw, gw+TW, ...; 64 of them are projected at a time, one per lane.  Lanes
   // = references while the run boxes are tested (one broadcast LDS read per run), then every (reference, run) hit is
   // visited with lanes = the 64 targets of the run.
-  for (int rb = wid; rb < nr; rb += MATCH_WAVES * 64) {
+  for (int rb = gw; rb < nr; rb += TW * 64) {
     double lpu = 0, lpv = 0;
-    const int rl = rb + MATCH_WAVES * lane;
+    const int rl = rb + TW * lane;
     if (rl < nr) {
       const double* X = fb.kp_xyz + (rbase + rl) * 3;
       const double u = dot4(RP, X[0], X[1], X[2], 1.0), v = dot4(RP + 4, X[0], X[1], X[2], 1.0), w = dot4(RP + 8, X[0], X[1], X[2], 1.0);
@@ -477,7 +496,7 @@ __global__ __launch_bounds__(MATCH_THREADS, MATCH_MIN_WAVES) void k_match(FrameB
       while (hm) {
         const int j = __ffsll((long long)hm) - 1;
         hm &= hm - 1ull;
-        const int r = rb + MATCH_WAVES * j;
+        const int r = rb + TW * j;
         const float fpu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lfpu), j));
         const float fpv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lfpv), j));
         bool cand = false;
@@ -504,6 +523,14 @@ __global__ __launch_bounds__(MATCH_THREADS, MATCH_MIN_WAVES) void k_match(FrameB
   }
   flush();
   __syncthreads();
+  if (nparts > 1) {  // hand the bests to k_match_finish
+    uint32_t* gbr = pb.mt_br + (size_t)pair * g.kp_total + G.kp_off;
+    uint32_t* gbt = pb.mt_bt + ((size_t)pair * MATCH_PARTS_MAX + part) * g.kp_total + G.kp_off;
+    for (int r = tid; r < nr; r += MATCH_THREADS)
+      if ((r % TW) / MATCH_WAVES == part) gbr[r] = s_br[r];
+    for (int t = tid; t < nt; t += MATCH_THREADS) gbt[t] = s_bt[t];
+    return;
+  }
   // mutual best matches in ref-index order, feature.cpp:6313-6333
   int32_t* lm_ref = pb.lm_ref + (size_t)pair * g.kp_total + G.kp_off;
   int32_t* lm_tgt = pb.lm_tgt + (size_t)pair * g.kp_total + G.kp_off;
@@ -520,6 +547,42 @@ __global__ __launch_bounds__(MATCH_THREADS, MATCH_MIN_WAVES) void k_match(FrameB
     }
     int total;
     const int pos = base + block_excl_scan<MATCH_WAVES>(flag, s_wave, &total);
+    if (flag) { lm_ref[pos] = r; lm_tgt[pos] = t; }
+    base += total;
+  }
+  if (tid == 0) pb.lm_cnt[pair * RVO_MAX_LEVELS + lvl] = base;
+}
+
+// grid (levels, n_pairs), 256 threads: the mutual matches of the levels k_match worked on in parts, in ref-index order
+// (feature.cpp:6313-6333); other levels were finished by k_match itself.
+__global__ __launch_bounds__(256) void k_match_finish(FrameBufs fb, FrameGeom g, PairBufs pb) {
+  __shared__ int s_wave[4];
+  const int lvl = blockIdx.x, pair = blockIdx.y + pb.pair0, tid = threadIdx.x;
+  if (!pb.active[pair]) return;
+  const LevelGeom G = g.lv[lvl];
+  const int nparts = match_parts(G.kp_cap);
+  if (nparts == 1) return;
+  const int rs = pb.ref_slot[pair];
+  const int nr = fb.kp_cnt[rs * RVO_MAX_LEVELS + lvl];
+  const uint32_t* gbr = pb.mt_br + (size_t)pair * g.kp_total + G.kp_off;
+  const uint32_t* gbt = pb.mt_bt + (size_t)pair * MATCH_PARTS_MAX * g.kp_total + G.kp_off;
+  int32_t* lm_ref = pb.lm_ref + (size_t)pair * g.kp_total + G.kp_off;
+  int32_t* lm_tgt = pb.lm_tgt + (size_t)pair * g.kp_total + G.kp_off;
+  int base = 0;
+  for (int c0 = 0; c0 < nr; c0 += 256) {
+    const int r = c0 + tid;
+    int flag = 0, t = 0;
+    if (r < nr) {
+      const uint32_t key = gbr[r];
+      if (key != NONE_KEY) {
+        t = key & 0xFFFF;
+        uint32_t best = NONE_KEY;
+        for (int p = 0; p < nparts; p++) best = min(best, gbt[(size_t)p * g.kp_total + t]);
+        flag = (int)(best & 0xFFFF) == r;
+      }
+    }
+    int total;
+    const int pos = base + block_excl_scan<4>(flag, s_wave, &total);
     if (flag) { lm_ref[pos] = r; lm_tgt[pos] = t; }
     base += total;
   }

@@ -76,6 +76,8 @@ struct rvo_ctx {
   int n_streams = 0;
   int32_t* d_sslots = nullptr;  // [2n]: current slot (-1 = warm-up skip), FAST threshold (device-written)
   int32_t* d_src_index = nullptr;  // rvo_streams_set_source_index: [stream] image of the step's arrays the stream reads
+  bool step_from_host = false;     // inside rvo_stream_step / rvo_stream_step_host_async
+  bool depth_in_place = false;     // rvo_streams_depth_in_place: rvo_stream_step_dev reads the caller's depth images where they lie
   int src_sources = 0;             // images those arrays hold then (0: no index, stream s reads image s)
   double* d_traj = nullptr;     // rvo_streams_record: [n_streams][traj_cap][RVO_TRAJ_DOUBLES]
   int traj_cap = 0, traj_steps = 0, traj_streams = 0;
@@ -606,10 +608,10 @@ static int ensure_stage(rvo_ctx* c, int n) {
 // read in place; the gray image too when its rows already have the level-0 stride and 16-byte alignment, and then
 // the launch only records the two pointers per slot.
 static int launch_ingest_on(rvo_ctx* c, hipStream_t st, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* d_slots,
-                            int copy, const int32_t* d_src_index = nullptr) {
+                            int copy, const int32_t* d_src_index = nullptr, int copy_gray_always = 0) {
   const FrameGeom& g = c->g;
   const bool vec = (g.W % 16 == 0) && (((size_t)g.Wd * g.Hd) % 8 == 0) && (((uintptr_t)gray & 15) == 0) && (((uintptr_t)depth & 15) == 0);
-  const int copy_gray = (copy || g.lv[0].stride != g.W || ((uintptr_t)gray & 15) != 0) ? 1 : 0;
+  const int copy_gray = (copy || copy_gray_always || g.lv[0].stride != g.W || ((uintptr_t)gray & 15) != 0) ? 1 : 0;
   const dim3 grid(copy_gray ? 16 : 1, n);
   if (vec) LAUNCH_ON(c, st, "ingest", k_ingest<true>, grid, dim3(256), 0, c->fb, g, gray, depth, d_slots, copy, copy_gray, d_src_index);
   else LAUNCH_ON(c, st, "ingest", k_ingest<false>, grid, dim3(256), 0, c->fb, g, gray, depth, d_slots, copy, copy_gray, d_src_index);

@@ -75,6 +75,8 @@ struct PairBufs {
   int32_t* lm_cnt;     // [pairs][RVO_MAX_LEVELS] matches per level
   int32_t* lm_ref;     // [pairs][kp_total] level segments at lv.kp_off
   int32_t* lm_tgt;
+  uint32_t* mt_br;     // [pairs][kp_total] k_match in parts: best (score << 16 | target) of every reference keypoint
+  uint32_t* mt_bt;     // [pairs][MATCH_PARTS_MAX][kp_total] per part: best (score << 16 | reference) of every target keypoint
   int32_t* n_matches;  // [pairs]
   int32_t* m_ref;      // [pairs][mcap] level-local keypoint index
   int32_t* m_tgt;

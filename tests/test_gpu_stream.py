@@ -362,3 +362,33 @@ def test_512_streams_on_one_context_configs2_default_shape(intr640):
         gt = np.linalg.inv(seqs[s % U][warm - 1][2]) @ seqs[s % U][T - 1][2]
         assert np.abs(traj[s, -1, :12].reshape(3, 4) - gt[:3]).max() < 5e-3, s
     ctx.close()
+
+
+def test_depth_read_in_place_equals_the_copying_step(scene, intr640):
+    """rvo_streams_depth_in_place: the step samples the caller's depth images where they lie instead of copying 614 KB per
+    frame into the slots; same trajectories, bit for bit, as the copying step (grouped steps, invalid depth in the mix,
+    nothing synchronised between the steps -- every frame's depth image stays resident until the end)."""
+    import torch
+    from slam_amd.api import Context, default_params
+    n, T = 40, 8
+    seqs = [list(synth.make_sequence(T, seed=170 + s, intr=intr640, scene=scene, invalid_frac=0.2 if s % 3 == 0 else 0.0)) for s in range(4)]
+    dg = torch.from_numpy(np.stack([np.stack([seqs[s % 4][t][0] for s in range(n)]) for t in range(T)])).cuda()
+    dd = torch.from_numpy(np.stack([np.stack([seqs[s % 4][t][1] for s in range(n)]) for t in range(T)]).view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    out = []
+    for in_place in (False, True):
+        ctx = Context(intr640, default_params(warmup_frames=1), max_frames=3 * n, max_pairs=n)
+        ctx.streams_reset(n)
+        if in_place:
+            ctx.streams_depth_in_place(True)
+        ctx.streams_record(T)
+        for t in range(T):
+            ctx.stream_step_dev(dg[t].data_ptr(), dd[t].data_ptr(), n)
+        out.append((ctx.trajectories(n, T), [(r["num_matches"], r["fast_thr"], r["cov"].tobytes()) for r in ctx.stream_results(n)]))
+        if in_place:  # a reset switches it off again
+            ctx.streams_reset(n)
+            ctx.stream_step_dev(dg[0].data_ptr(), dd[0].data_ptr(), n)
+            ctx.sync()
+        ctx.close()
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    assert (out[0][0][:, 1:, 12] == 1).all()

@@ -32,6 +32,7 @@ if __name__ == "__main__":
     ctxs = [Context(intr, p, max_frames=3 * per, max_pairs=per) for _ in range(NC)]
     for c in ctxs:
         c.streams_reset(per)
+        if os.environ.get('RVO_DEPTH_IN_PLACE', '1') != '0': c.streams_depth_in_place(True)
         c.set_pair_chunks(1 if NC > 1 else int(os.environ.get('RVO_PAIR_CHUNKS', '2')))
     torch.cuda.synchronize()
     order = list(range(T)) + list(range(T - 2, 0, -1))

@@ -67,6 +67,7 @@ def main():
         c = Context(INTR, p, max_frames=3 * len(h), max_pairs=len(h), device=dev_index)
         c.streams_reset(len(h))
         c.streams_set_source_index(UNIQUE, [mine[k] % UNIQUE for k in h])
+        c.streams_depth_in_place(True)  # all frames of the run are resident: depth is sampled where it lies
         c.set_pair_chunks(1)
         ctxs.append(c)
     for c, h in zip(ctxs, halves):
