@@ -930,25 +930,8 @@ __global__ __launch_bounds__(256) void k_build_keypoints(FrameBufs fb, FrameGeom
     }
   }
   if (tid == 0) fb.kp_cnt[slot * RVO_MAX_LEVELS + lvl] = base;
-  // Descriptors of the keypoints that survived: their rows of bk_desc (written by k_fast_grid) are copied into the
-  // level's compact order, one 16-byte piece per thread and trip, five consecutive threads per keypoint, BK_CP trips'
-  // loads in flight at a time.  (Was a kernel of its own; here it costs no launch.)  The kp_src entries were written by
-  // other threads of this workgroup.
-  __syncthreads();
-  for (int t0 = 0; t0 < base * 5; t0 += 256 * BK_CP) {  // (loads with clamped indices for every lane, see above)
-    uint4 v[BK_CP];
-    int idx[BK_CP], piece[BK_CP], src[BK_CP];
-#pragma unroll
-    for (int u = 0; u < BK_CP; u++) {
-      const int t = min(t0 + u * 256 + tid, base * 5 - 1);
-      idx[u] = t / 5; piece[u] = t - idx[u] * 5;
-      src[u] = fb.kp_src[kbase + idx[u]];
-    }
-#pragma unroll
-    for (int u = 0; u < BK_CP; u++) v[u] = reinterpret_cast<const uint4*>(fb.bk_desc + (kbase + src[u]) * RVO_DESC_LEN)[piece[u]];
-#pragma unroll
-    for (int u = 0; u < BK_CP; u++)
-      if (t0 + u * 256 + tid < base * 5) reinterpret_cast<uint4*>(fb.kp_desc + (kbase + idx[u]) * RVO_DESC_LEN)[piece[u]] = v[u];
-  }
+  // The survivors' descriptors stay where k_fast_grid wrote them (bk_desc, bucket order): kp_src names the row, k_match
+  // reads through it.  (Rounds 1-2 copied the rows into keypoint order here: 160 B of traffic per keypoint and half of
+  // this kernel's time.)
 }
 

@@ -457,7 +457,8 @@ __global__ __launch_bounds__(MATCH_THREADS, MATCH_MIN_WAVES) void k_match(FrameB
     for (int e = lane; e < qn; e += 64) {
       const uint32_t rt = s_q[e];
       const uint32_t r = rt >> 16, t = rt & 0xFFFF;
-      const uint32_t s = sad80(fb.kp_desc + (rbase + r) * RVO_DESC_LEN, fb.kp_desc + (tbase + t) * RVO_DESC_LEN);
+      // a kept keypoint's descriptor stays where k_fast_grid wrote it (bucket order): row kp_src[] of the level's block
+      const uint32_t s = sad80(fb.bk_desc + (rbase + fb.kp_src[rbase + r]) * RVO_DESC_LEN, fb.bk_desc + (tbase + fb.kp_src[tbase + t]) * RVO_DESC_LEN);
       atomicMin(&s_br[r], (s << 16) | t);
       atomicMin(&s_bt[t], (s << 16) | r);
     }

@@ -440,7 +440,6 @@ static int ctx_init(rvo_ctx* c, const rvo_intrinsics* intr, const rvo_params* pr
   rc |= dalloc(c, &fb.kp_rect, F * g.kp_total);
   rc |= dalloc(c, &fb.kp_track, F * g.kp_total);
   rc |= dalloc(c, &fb.kp_xyz, F * g.kp_total * 3);
-  rc |= dalloc(c, &fb.kp_desc, F * g.kp_total * RVO_DESC_LEN + 64);
   rc |= dalloc(c, &fb.bk_desc, F * g.kp_total * RVO_DESC_LEN + 64);
   rc |= dalloc(c, &fb.kp_src, F * g.kp_total);
   rc |= dalloc(c, &fb.kp_cnt, F * RVO_MAX_LEVELS);
@@ -777,8 +776,14 @@ int rvo_get_descriptors(rvo_ctx* c, int slot, int level, uint8_t* out) {
   const FrameGeom& g = c->g;
   int32_t n = 0;
   HIPCHK(hipMemcpy(&n, c->fb.kp_cnt + slot * RVO_MAX_LEVELS + level, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(out, c->fb.kp_desc + ((size_t)slot * g.kp_total + g.lv[level].kp_off) * RVO_DESC_LEN, (size_t)n * RVO_DESC_LEN,
-                   hipMemcpyDeviceToHost));
+  if (n <= 0) return RVO_OK;
+  // descriptors lie in bucket order (bk_desc); kp_src names each kept keypoint's row of the level's block
+  const size_t kb = (size_t)slot * g.kp_total + g.lv[level].kp_off;
+  std::vector<uint16_t> src((size_t)n);
+  std::vector<uint8_t> rows((size_t)g.lv[level].kp_cap * RVO_DESC_LEN);
+  HIPCHK(hipMemcpy(src.data(), c->fb.kp_src + kb, (size_t)n * 2, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(rows.data(), c->fb.bk_desc + kb * RVO_DESC_LEN, rows.size(), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) memcpy(out + (size_t)i * RVO_DESC_LEN, rows.data() + (size_t)src[i] * RVO_DESC_LEN, RVO_DESC_LEN);
   return RVO_OK;
 }
 

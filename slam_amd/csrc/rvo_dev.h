@@ -51,9 +51,8 @@ struct FrameBufs {
   uint32_t* kp_uvs;   // [slots][kp_total] packed keypoints after the border/LUT/depth filter
   float2* kp_rect;    // [slots][kp_total] rect_base_uv (LUT values are floats, exact)
   double* kp_xyz;     // [slots][kp_total][3]
-  uint8_t* kp_desc;   // [slots][kp_total][80]
   uint8_t* bk_desc;   // [slots][total_buckets][max_per][80] descriptors of the grid-filtered keypoints, extracted by
-                      // k_fast_grid from its LDS tile; k_descriptors copies the survivors' rows into kp_desc
+                      // k_fast_grid from its LDS tile; kp_src names the row of every keypoint that survived k_build_keypoints
   int32_t* kp_track;  // [slots][kp_total] KeypointData::track_id: -1 after Frame::Prepare (frame.cpp:138), then what
                       // MotionEstimator::matchFeatures / EstimateMotion leave (motion_estimate.cpp:216-222, 380-391)
   uint16_t* kp_src;   // [slots][kp_total] level-local bucket slot (bucket * max_per + j) each kept keypoint came from
