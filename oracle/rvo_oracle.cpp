@@ -1657,6 +1657,32 @@ void orc_std_select_or_sort(uint32_t* keys, int n, int shift, int nth) {
   for (int i = 0; i < n; i++) keys[i] = v[i].full;
 }
 
+// ---- test hooks into the Gauss-Newton pieces (tests/test_cpu_gn.py: analytic Jacobians against finite differences of an
+// independent residual, the refined pose against scipy.optimize.least_squares).  n points each way; xyz arrays are n x 4
+// (homogeneous), projections n x 2.
+void orc_gn_residuals(const double* prm6, int n, const double* txyz, const double* rproj, const double* rxyz, const double* tproj,
+                      double fx, double px, double py, double* err /* 4n: forward u,v per point, then reverse */) {
+  std::vector<double> a(txyz, txyz + 4 * n), b(rproj, rproj + 2 * n), c2(rxyz, rxyz + 4 * n), d(tproj, tproj + 2 * n);
+  Iso m = iso_from_params(prm6);
+  reproj_error(a, b, fx, px, py, m, err);
+  reproj_error(c2, d, fx, px, py, iso_inverse(m), err + 2 * n);
+}
+void orc_gn_jacobian(const double* prm6, int n, const double* txyz, const double* rxyz, double fx, double px, double py,
+                     double* M /* 4n x 6, rows as orc_gn_residuals */) {
+  JacMats f, r;
+  forward_jac_mats(prm6, fx, px, py, &f);
+  reverse_jac_mats(prm6, fx, px, py, &r);
+  for (int i = 0; i < n; i++) jac_rows(f, txyz + 4 * i, M + (2 * i) * 6, M + (2 * i + 1) * 6);
+  for (int i = 0; i < n; i++) jac_rows(r, rxyz + 4 * i, M + (2 * n + 2 * i) * 6, M + (2 * n + 2 * i + 1) * 6);
+}
+void orc_params_to_pose(const double* prm6, double* pose3x4) { iso_to_3x4(iso_from_params(prm6), pose3x4); }
+void orc_pose_to_params(const double* pose3x4, double* prm6) { iso_to_params(iso_from_3x4(pose3x4), prm6); }
+// camera the estimator works with (the rectified one: fx, fy, cx, cy)
+void orc_rect_camera(void* cv, double* out4) {
+  const Intrinsics& r = ((Ctx*)cv)->cam.rect;
+  out4[0] = r.fx; out4[1] = r.fy; out4[2] = r.cx; out4[3] = r.cy;
+}
+
 // ---- streaming VO
 void* orc_vo_create(void* cv, int base_slot) { return new VO((Ctx*)cv, base_slot); }
 void orc_vo_destroy(void* v) { delete (VO*)v; }
