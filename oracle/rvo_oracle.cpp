@@ -888,6 +888,7 @@ struct MotionEstimator {
   Frame* ref = nullptr;
   Frame* tgt = nullptr;
   Margins mg;
+  int rot_iters = 0, rot_best_iter = 0;  // last EstimateInitialRotation: iterations run, iteration whose H was returned
   int num_tracks = 0;  // motion_estimate.cpp:116: one counter per MotionEstimator (per RGBDVO / per FrameMatcher)
 
   MotionEstimator(const Camera* c, const Params* p) : cam(c), prm(p) {
@@ -1338,6 +1339,7 @@ struct MotionEstimator {
       memcpy(H, Hn, sizeof(H));
       if (rms < lastRMS) lastImproved = iter;
       double lnorm = sqrt((double)((float)lie[0] * (float)lie[0] + (float)lie[1] * (float)lie[1] + (float)lie[2] * (float)lie[2]));
+      rot_iters = iter + 1; rot_best_iter = bestIter;  // (test instrumentation: orc_initial_rotation_info)
       if (lnorm < 1e-6 || (rms - minError > 3 && iter - bestIter > 2) || iter - bestIter > 4 || iter - lastImproved > 2) break;
       lastRMS = rms;
     }
@@ -1585,6 +1587,12 @@ void orc_initial_rotation(void* cv, int prev_slot, int cur_slot, double* q_wxyz)
   Ctx* c = (Ctx*)cv;
   Quat q = c->est.EstimateInitialRotation(c->slot(prev_slot), c->slot(cur_slot));
   q_wxyz[0] = q.w; q_wxyz[1] = q.x; q_wxyz[2] = q.y; q_wxyz[3] = q.z;
+}
+
+// iterations the last EstimateInitialRotation ran and the one whose H it returned (tests/test_cpu_initial_rotation.py)
+void orc_initial_rotation_info(void* cv, int32_t* out2) {
+  Ctx* c = (Ctx*)cv;
+  out2[0] = c->est.rot_iters; out2[1] = c->est.rot_best_iter;
 }
 
 // MotionEstimator::EstimateMotion with an explicit initial estimate (3x4 row-major)
