@@ -179,12 +179,30 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
   const int tid = threadIdx.x;
   const uint32_t M = 0x00FF00FFu;
 
-  for (int i = tid; i < PYR_SROWS * (PYR_SCOLS / 16); i += 256) {
-    const int r = i / (PYR_SCOLS / 16), c16 = i % (PYR_SCOLS / 16);
-    const int gy = sy0 + r, gx = sx0 + 16 * c16;  // multiple of 16; level strides are multiples of 16
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (gy >= 0 && gy < S.h && gx >= 0 && gx < S.stride) v = gload_u4(src + (size_t)gy * S.stride + gx);
-    *reinterpret_cast<uint4*>(&s_src[r][16 * c16]) = v;
+  {
+    // all of a thread's loads (three) are issued before the first store: the loop form waited for every load in turn, three
+    // serial round trips to memory per workgroup.  Addresses are clamped into the image and the loads unpredicated; what
+    // lies outside the image is staged as zeros as before.
+    constexpr int NITEMS = PYR_SROWS * (PYR_SCOLS / 16), NLD = (NITEMS + 255) / 256;
+    uint4 v[NLD];
+    bool ok[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; u++) {
+      const int i = tid + 256 * u;
+      const int r = i / (PYR_SCOLS / 16), c16 = i % (PYR_SCOLS / 16);
+      const int gy = sy0 + r, gx = sx0 + 16 * c16;  // multiple of 16; level strides are multiples of 16
+      ok[u] = gy >= 0 && gy < S.h && gx >= 0 && gx < S.stride;
+      const int cy = min(max(gy, 0), S.h - 1), cx = min(max(gx, 0), S.stride - 16);
+      v[u] = gload_u4(src + (uint32_t)(cy * S.stride + cx));
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; u++) {
+      const int i = tid + 256 * u;
+      if (i < NITEMS) {
+        const int r = i / (PYR_SCOLS / 16), c16 = i % (PYR_SCOLS / 16);
+        *reinterpret_cast<uint4*>(&s_src[r][16 * c16]) = ok[u] ? v[u] : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
   }
   __syncthreads();
   // pass 1: along x (source rows -> s_mid), what the reference stores transposed in pyrbuf.  Every group of four takes
