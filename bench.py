@@ -229,6 +229,15 @@ def run_stream_leg(seqs, dev_index, steps, warmup, log, oracle_streams=2, oracle
                 oracle_steps_identical=same, oracle_steps_checked=total)
 
 
+def latest_profile(name: str) -> str:
+    """profiles/rNN_<name> of the newest round that has one (the committed rocprofv3 --pmc summaries of this command)."""
+    for rnd in ("r03", "r02", "r01"):
+        p = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", f"r03_{name}")
+
+
 def algorithmic_bytes(geom: dict, stats: dict) -> dict:
     """Algorithmic HBM bytes per LAUNCH of each kernel kind (definitions: DESIGN.md section 5)."""
     W, H, L = geom["W"], geom["H"], geom["levels"]
@@ -238,10 +247,10 @@ def algorithmic_bytes(geom: dict, stats: dict) -> dict:
     B = {}
     B["pyr_down"] = nf * sum(lv[l - 1] + lv[l] for l in range(1, L)) / max(1, L - 1)
     B["fast_grid"] = nf * (sum(lv) + geom["total_buckets"] * (geom["max_per"] * (4 + 80) + 8))
-    # bucket lists in, keypoint records out, and the descriptor rows moved from bucket order to keypoint order (80 B each way)
-    B["build_keypoints"] = nf * (geom["total_buckets"] * (geom["max_per"] * 4 + 8) + K * (36 + 8 + 4 + 2 + 8) + K * (2 + 80 + 80))
+    # bucket lists in, keypoint records out (the descriptor rows stay in bucket order since round 3: kp_src names them)
+    B["build_keypoints"] = nf * (geom["total_buckets"] * (geom["max_per"] * 4 + 8) + K * (36 + 8 + 4 + 2 + 8) + K * 2)
     B["init_rotation"] = npair * 2 * lv[L - 1]
-    B["match"] = npair * (2 * K * 80 + 2 * K * 32 + N * 8)
+    B["match"] = npair * (2 * K * 80 + 2 * K * (32 + 2) + N * 8)
     B["refine"] = npair * N * (2 * 100 + 20)
     B["refine_finish"] = npair * N * (20 + 100)
     B["consistency"] = npair * (N * N / 8 + N * 48)
@@ -373,7 +382,7 @@ def main():
         # Inside the pipeline every launch is stretched by whatever runs beside it (k_refine: 0.15 ms alone, 0.5 ms here),
         # so "dominant" is decided by the work a kernel does, not by how long it was resident: the largest VALU issue
         # time per batch in the committed SQ counters of this command, if that file is there
-        sp0 = os.path.join(ROOT, "profiles", "r02_sq_counters.csv")
+        sp0 = latest_profile("sq_counters.csv")
         if wp and os.path.exists(sp0):
             import csv
             issue = {r["kernel"]: float(r["valu_issue_ms_at_2.4GHz"]) * int(r["launches_per_batch"]) for r in csv.DictReader(open(sp0))}
@@ -464,14 +473,14 @@ def main():
             avg_s = prof_dom[dom]["total_ms"] / prof_dom[dom]["calls"] * 1e-3
             ach = B[dom] / avg_s
             # HBM traffic per launch: not measurable from inside this process; taken from the committed rocprofv3
-            # --pmc passes of this same command (profiles/r02_pmc_traffic.json), valid for the default launch shape
+            # --pmc passes of this same command (profiles/rNN_pmc_traffic.json), valid for the default launch shape
             traffic, traffic_src = None, None
-            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+            tp = latest_profile("pmc_traffic.json")
             if os.path.exists(tp) and n_pairs == 256 and n_ctx == 1 and not os.environ.get("RVO_PAIR_CHUNKS"):
                 tj = json.load(open(tp))
                 if dom in tj["kernels"]:
                     traffic = tj["kernels"][dom]["traffic_bytes"]
-                    traffic_src = "profiles/r02_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, separate --pmc passes"
+                    traffic_src = f"profiles/{os.path.basename(tp)}: (2*FETCH_SIZE + WRITE_SIZE) KiB per dispatch, separate --pmc passes"
             roof = dict(bound="hbm", kernel=dom, achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                         frac=ach / HBM_PEAK, traffic=traffic, traffic_source=traffic_src, avg_launch_ms=avg_s * 1e3,
                         launches_timed=prof_dom[dom]["calls"],
@@ -482,12 +491,12 @@ def main():
         # VALU issue roofline (the bound that actually holds for this path): issue time per batch from
         # the committed SQ counters of this same command (a --pmc pass of its own) against the live batch time
         roof_valu = None
-        sp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_sq_counters.csv")
+        sp = latest_profile("sq_counters.csv")
         if os.path.exists(sp) and n_pairs == 256 and n_ctx == 1 and not os.environ.get("RVO_PAIR_CHUNKS"):
             import csv
             issue_ms = sum(float(r["valu_issue_ms_at_2.4GHz"]) * int(r["launches_per_batch"]) for r in csv.DictReader(open(sp)))
             roof_valu = dict(bound="valu-issue", issue_ms_per_batch=issue_ms, frac=issue_ms / (dt / a.steps * 1e3),
-                             source="profiles/r02_sq_counters.csv: SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz per launch, "
+                             source=f"profiles/{os.path.basename(sp)}: SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz per launch, "
                                     "summed over the launches of one batch")
         kernels = {k: dict(avg_ms=v["total_ms"] / v["calls"], calls=v["calls"],
                            GBps=(B[k] / (v["total_ms"] / v["calls"] * 1e-3) / 1e9) if k in B else None)

@@ -8,7 +8,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 shutil.copy(f"gpurun_out/prof_{tag}/{tag}_kernel_stats.csv", f"profiles/{rnd}_{tag}_kernel_stats.csv")
 line = open(f"gpurun_out/bench_{tag}.json").read().strip().splitlines()[-1]
 open(f"profiles/{rnd}_{tag}_bench.json", "w").write(line + "\n")
@@ -23,9 +23,9 @@ for ctr, f in (("FETCH_SIZE", "gpurun_out/pmc_fetch/f_counter_collection.csv"),
     out[ctr] = {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
 
 names = {"k_ingest": "ingest", "k_stream_post": "stream_post", "k_stream_post2": "stream_post2", "k_pyr_down": "pyr_down", "k_fast_grid": "fast_grid", "k_build_keypoints": "build_keypoints",
-         "k_descriptors": "descriptors", "k_init_rotation": "init_rotation", "k_match": "match", "k_refine": "refine",
+         "k_descriptors": "descriptors", "k_init_rotation": "init_rotation", "k_match": "match", "k_match_finish": "match_finish", "k_refine": "refine",
          "k_refine_finish": "refine_finish", "k_consistency": "consistency", "k_clique": "clique", "k_clique_walk": "clique_walk", "k_gn": "gauss_newton", "k_track_count": "track_count", "k_track_assign": "track_assign"}
-res = json.load(open(f"profiles/{rnd}_pmc_traffic.json")) if os.path.exists(f"profiles/{rnd}_pmc_traffic.json") else dict(json.load(open("profiles/r01_pmc_traffic.json")), source_tag=tag)
+res = json.load(open(f"profiles/{rnd}_pmc_traffic.json")) if os.path.exists(f"profiles/{rnd}_pmc_traffic.json") else dict(json.load(open("profiles/r02_pmc_traffic.json")), source_tag=tag)
 res["kernels"] = {}
 for k, n in names.items():
     if k not in out["FETCH_SIZE"]:
