@@ -156,8 +156,14 @@ __device__ inline int gauss_tap(F at, int n, int r) {
 // gray_inplace / depth_inplace (rvo_match_frames_dev, lvl == 1 only, else null): the batch's images, read where they
 // lie; the launch then also records them as the slots' level-0 / depth images (what k_ingest would do in a launch of
 // its own), for the kernels that follow on the stream.
+// src_index (with gray_inplace, may be null): frame fi reads image src_index[fi] of the caller's arrays.
+// copy_l0 (with gray_inplace; the stream step with depth read in place): the level-0 image must outlive the caller's buffer
+// (a stream's frame is the reference / previous frame of later steps), so every tile also writes the 128 x 64 level-0
+// pixels under it from its staged window into the slot's own image -- the copy k_ingest made in a launch and a pass over
+// the image of its own (the tiles' interiors cover the image: W, H even).
 __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, const int32_t* __restrict__ slots, int lvl,
-                                                  const uint8_t* __restrict__ gray_inplace, const uint16_t* __restrict__ depth_inplace) {
+                                                  const uint8_t* __restrict__ gray_inplace, const uint16_t* __restrict__ depth_inplace,
+                                                  const int32_t* __restrict__ src_index, int copy_l0) {
   RVO_OCC_SCOPE(1, 16);
   const LevelGeom S = g.lv[lvl - 1], D = g.lv[lvl];
   int tile, fi;  // XCD-aware: the tiles of a frame share source lines
@@ -165,10 +171,12 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
   const int tile_y = (tile * (int)kInv16.v[gridDim.x]) >> 16, tile_x = tile - tile_y * (int)gridDim.x;  // tile / gridDim.x (tile < 512)
   const int slot = slots[fi];
   if (slot < 0) return;  // stream still in warm-up (vo.cpp:58-69)
-  const uint8_t* __restrict__ src = gray_inplace ? gray_inplace + (size_t)fi * g.W * g.H : level_img(fb, g, slot, lvl - 1);
+  const int fsrc = (gray_inplace && src_index) ? src_index[fi] : fi;
+  const uint8_t* __restrict__ src = gray_inplace ? gray_inplace + (size_t)fsrc * g.W * g.H : level_img(fb, g, slot, lvl - 1);
+  uint8_t* __restrict__ l0_own = fb.img + (size_t)slot * g.img_bytes + g.lv[0].img_off;
   if (gray_inplace && tile == 0 && threadIdx.x == 0) {
-    fb.l0_tab[slot] = src;
-    fb.depth_tab[slot] = depth_inplace + (size_t)fi * g.Wd * g.Hd;
+    fb.l0_tab[slot] = copy_l0 ? l0_own : src;
+    fb.depth_tab[slot] = depth_inplace + (size_t)fsrc * g.Wd * g.Hd;
   }
   uint8_t* __restrict__ dst = fb.img + (size_t)slot * g.img_bytes + D.img_off;
   const int dw = S.w / 2, dh = S.h / 2;
@@ -201,6 +209,9 @@ __global__ __launch_bounds__(256) void k_pyr_down(FrameBufs fb, FrameGeom g, con
       if (i < NITEMS) {
         const int r = i / (PYR_SCOLS / 16), c16 = i % (PYR_SCOLS / 16);
         *reinterpret_cast<uint4*>(&s_src[r][16 * c16]) = ok[u] ? v[u] : make_uint4(0u, 0u, 0u, 0u);
+        // the tile's own 128 x 64 source pixels: staged rows 2..65, bytes 16..143
+        if (copy_l0 && ok[u] && r >= 2 && r < 2 + 2 * PYR_TH && c16 >= 1 && c16 <= 2 * PYR_TW / 16)
+          *reinterpret_cast<uint4*>(l0_own + (size_t)(sy0 + r) * S.stride + (sx0 + 16 * c16)) = v[u];
       }
     }
   }

@@ -625,12 +625,13 @@ static int launch_ingest(rvo_ctx* c, int n, const uint8_t* gray, const uint16_t*
 // gray / depth non-null: the images are read in place (see can_read_in_place) and the first launch records them as the
 // slots' level-0 / depth images.
 static int enqueue_pyramid_on(rvo_ctx* c, hipStream_t st, int n, const int32_t* d_slots, const uint8_t* gray = nullptr,
-                              const uint16_t* depth = nullptr) {
+                              const uint16_t* depth = nullptr, const int32_t* d_src_index = nullptr, int copy_l0 = 0) {
   const FrameGeom& g = c->g;
   for (int l = 1; l < g.levels; l++) {
     const int dw = g.lv[l - 1].w / 2, dh = g.lv[l - 1].h / 2;
     dim3 grid((dw + PYR_TW - 1) / PYR_TW, (dh + PYR_TH - 1) / PYR_TH, n);
-    LAUNCH_ON(c, st, "pyr_down", k_pyr_down, grid, dim3(256), 0, c->fb, g, d_slots, l, l == 1 ? gray : nullptr, l == 1 ? depth : nullptr);
+    LAUNCH_ON(c, st, "pyr_down", k_pyr_down, grid, dim3(256), 0, c->fb, g, d_slots, l, l == 1 ? gray : nullptr, l == 1 ? depth : nullptr,
+              l == 1 ? d_src_index : nullptr, l == 1 ? copy_l0 : 0);
   }
   return RVO_OK;
 }
