@@ -612,11 +612,10 @@ __device__ inline int interp_raw(const uint8_t* __restrict__ gimg, int stride, c
   const float f = ((w.wa * (float)gimg[k] + w.wb * (float)gimg[k + 1]) + w.wc * (float)gimg[k + stride]) + w.wd * (float)gimg[k + stride + 1];
   return (int)f;  // (uint8_t) truncation; f is in [0, 256)
 }
-__device__ inline int norm_px(int v, int mean) {  // Descriptor::Normalized, feature.cpp:6158-6178
-  if (mean < 128) return min(255, v + (128 - mean));
-  if (mean > 128) return max(0, v - (mean - 128));
-  return v;
-}
+// Descriptor::Normalized, feature.cpp:6158-6178: mean < 128 adds 128 - mean and saturates at 255, mean > 128 subtracts
+// mean - 128 and saturates at 0 -- for a byte v both are clamp(v + (128 - mean), 0, 255) (the bound that cannot be
+// reached never binds), one add and one v_med3 instead of two compares and selects
+__device__ inline int norm_px(int v, int mean) { return min(max(v + (128 - mean), 0), 255); }
 
 #ifndef REFINE_GROUP
 #define REFINE_GROUP 16  // lanes per match; 8 (10 taps per lane) needs 172 VGPRs and measured 28 % slower
@@ -744,25 +743,35 @@ __global__ __launch_bounds__(REFINE_THREADS, REFINE_MIN_WAVES) void k_refine(Fra
   }
   const int rmean = group16_sum(rsum) / RVO_DESC_LEN;
   const int tmean = group16_sum(tsum) / RVO_DESC_LEN;
-  int rn[REFINE_TAPS], te[REFINE_TAPS];  // te = error of the current target descriptor against the reference's
-  int final_sse = 0;
-#pragma unroll
-  for (int m = 0; m < REFINE_TAPS; m++) {
-    rn[m] = norm_px(rraw[m], rmean);
-    te[m] = norm_px(traw[m], tmean) - rn[m];
-    final_sse += te[m] * te[m];
-  }
-  final_sse = group16_sum(final_sse);
-  const int min_xy = RVO_WIN, max_x = G.w - RVO_WIN - 2, max_y = G.h - RVO_WIN - 2;  // pyramid.cpp:123-126
-  for (int it = 0; it < 6; it++) {
-    int S00 = 0, S01 = 0, S11 = 0, gxs = 0, gys = 0;
+  // The lane's five taps as i16 pairs (|values| <= 510): the sums of products below are v_dot2_i32_i16, two taps per
+  // instruction, exact in int32 like the reference's dot_int16_aligned (motion_estimate.cpp:723-755)
+  static_assert(REFINE_TAPS == 5, "pairs (0,1), (2,3) and tap 4 below");
+  struct P5 { s2_t a, b; int c; };
+  auto pack5 = [](const int* v) { P5 p; p.a = s2_t{(short)v[0], (short)v[1]}; p.b = s2_t{(short)v[2], (short)v[3]}; p.c = v[4]; return p; };
+  auto dot5 = [](const P5& x, const P5& y) { return __builtin_amdgcn_sdot2(x.a, y.a, __builtin_amdgcn_sdot2(x.b, y.b, x.c * y.c, false), false); };
+  int rn[REFINE_TAPS];
+  P5 te;  // te = error of the current target descriptor against the reference's
+  {
+    int e[REFINE_TAPS];
 #pragma unroll
     for (int m = 0; m < REFINE_TAPS; m++) {
-      const int mx = rdx[m] + (tnb[m].p01 - tnb[m].p00);
-      const int my = rdy[m] + (tnb[m].p10 - tnb[m].p00);
-      S00 += mx * mx; S01 += mx * my; S11 += my * my; gxs += mx * te[m]; gys += my * te[m];
+      rn[m] = norm_px(rraw[m], rmean);
+      e[m] = norm_px(traw[m], tmean) - rn[m];
     }
-    S00 = group16_sum(S00); S01 = group16_sum(S01); S11 = group16_sum(S11); gxs = group16_sum(gxs); gys = group16_sum(gys);
+    te = pack5(e);
+  }
+  int final_sse = group16_sum(dot5(te, te));
+  const int min_xy = RVO_WIN, max_x = G.w - RVO_WIN - 2, max_y = G.h - RVO_WIN - 2;  // pyramid.cpp:123-126
+  for (int it = 0; it < 6; it++) {
+    int mxv[REFINE_TAPS], myv[REFINE_TAPS];
+#pragma unroll
+    for (int m = 0; m < REFINE_TAPS; m++) {
+      mxv[m] = rdx[m] + (tnb[m].p01 - tnb[m].p00);
+      myv[m] = rdy[m] + (tnb[m].p10 - tnb[m].p00);
+    }
+    const P5 mx = pack5(mxv), my = pack5(myv);
+    const int S00 = group16_sum(dot5(mx, mx)), S01 = group16_sum(dot5(mx, my)), S11 = group16_sum(dot5(my, my));
+    const int gxs = group16_sum(dot5(mx, te)), gys = group16_sum(dot5(my, te));
     const double s00 = S00, s01 = S01, s11 = S11;
     const double det = s00 * s11 - s01 * s01;
     if (det <= 1e-9) break;
@@ -787,17 +796,16 @@ __global__ __launch_bounds__(REFINE_THREADS, REFINE_MIN_WAVES) void k_refine(Fra
 #pragma unroll
     for (int m = 0; m < REFINE_TAPS; m++) { nraw[m] = interp(wn, m, nnb[m]); nsum += nraw[m]; }
     const int nmean = group16_sum(nsum) / RVO_DESC_LEN;
-    int sse = 0, ne[REFINE_TAPS];
+    int nev[REFINE_TAPS];
 #pragma unroll
-    for (int m = 0; m < REFINE_TAPS; m++) {
-      ne[m] = norm_px(nraw[m], nmean) - rn[m];
-      sse += ne[m] * ne[m];
-    }
-    sse = group16_sum(sse);
+    for (int m = 0; m < REFINE_TAPS; m++) nev[m] = norm_px(nraw[m], nmean) - rn[m];
+    const P5 ne = pack5(nev);
+    const int sse = group16_sum(dot5(ne, ne));
     if (sse < final_sse) {
       tx = ntx; ty = nty; final_sse = sse;
+      te = ne;
 #pragma unroll
-      for (int m = 0; m < REFINE_TAPS; m++) { te[m] = ne[m]; tnb[m] = nnb[m]; }
+      for (int m = 0; m < REFINE_TAPS; m++) tnb[m] = nnb[m];
     } else break;
     if (fabs(dxs) < 0.1 && fabs(dys) < 0.1) break;
   }
