@@ -285,6 +285,12 @@ int rvo_get_matches(rvo_ctx* ctx, int pair, int cap, int32_t* ints, double* dbl)
  * it and reused by the later ones; rvo_match_frames_dev requires distinct slots.  Every stream of rvo_stream_step has a
  * counter of its own (RGBDVO's estimator, vo.hpp:96).  Returns the number of rows written. */
 int rvo_get_match_tracks(rvo_ctx* ctx, int pair, int cap, int32_t* track_ids);
+/* FeatureMatch::consistency_vec and compatibility_degree (rgbdvo/feature.hpp:262-270, filled by
+ * computeMaximallyConsistentClique, motion_estimate.cpp:470-523): out[i * n + id] = 1 iff the match in row i (rows as
+ * rvo_get_matches writes them) is rigidly consistent with the match whose id is `id` (0 on the diagonal); n = the
+ * pair's number of matches, cap >= n * n bytes.  The library keeps the N x N relation as a bit matrix; this unpacks it into
+ * the reference's layout.  Returns n, or a negative error. */
+int rvo_get_match_consistency(rvo_ctx* ctx, int pair, int cap, uint8_t* out);
 /* KeypointData::track_id of the keypoints of a slot's level (rgbdvo/feature.hpp:75; -1 = none, frame.cpp:138), rows as
  * rvo_get_keypoints writes them.  Returns the number of rows written. */
 int rvo_get_keypoint_tracks(rvo_ctx* ctx, int slot, int level, int32_t* track_ids);

@@ -207,6 +207,12 @@ class Oracle:
         self.L.orc_get_match_tracks(self.h, C.c_int(n), _p(out))
         return out
 
+    def match_consistency(self, n):
+        """consistency_vec of the last EstimateMotion's matches: [n, n] u8, rows as matches(), columns = ids."""
+        out = np.zeros((n, n), np.uint8)
+        self.L.orc_get_match_consistency(self.h, C.c_int(n), _p(out))
+        return out
+
     def keypoint_tracks(self, slot, level):
         out = np.zeros(self.level_info(slot, level)["num_keypoints"], np.int32)
         self.L.orc_level_tracks(self.h, C.c_int(slot), C.c_int(level), _p(out))

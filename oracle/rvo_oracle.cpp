@@ -1622,6 +1622,12 @@ void orc_level_tracks(void* cv, int slot, int level, int32_t* out) {
   const Level& lv = ((Ctx*)cv)->slot(slot)->levels[level];
   for (size_t i = 0; i < lv.kps.size(); i++) out[i] = lv.kps[i].track_id;
 }
+// FeatureMatch::consistency_vec of the last EstimateMotion's matches (rows as orc_get_matches, columns = ids): n x n bytes
+void orc_get_match_consistency(void* cv, int n, uint8_t* out) {
+  Ctx* c = (Ctx*)cv;
+  for (size_t i = 0; i < c->est.matches.size() && (int)i < n; i++)
+    for (int j = 0; j < n; j++) out[i * n + j] = (uint8_t)c->est.matches[i].consistency_vec[j];
+}
 int orc_num_tracks(void* cv) { return ((Ctx*)cv)->est.num_tracks; }
 void orc_set_num_tracks(void* cv, int n) { ((Ctx*)cv)->est.num_tracks = n; }
 

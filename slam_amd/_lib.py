@@ -51,7 +51,7 @@ SYMBOLS = [
     "rvo_stream_step", "rvo_stream_step_dev", "rvo_get_stream_results", "rvo_stream_results_dev",
     "rvo_get_stream_slots",
     "rvo_get_level_info", "rvo_get_level_image", "rvo_get_grid_keypoints", "rvo_get_keypoints",
-    "rvo_stream_step_host_async", "rvo_wait_upload", "rvo_host_alloc", "rvo_host_free", "rvo_get_descriptors", "rvo_get_matches", "rvo_get_match_tracks", "rvo_get_keypoint_tracks", "rvo_reset_tracks", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_select", "rvo_profile_read",
+    "rvo_stream_step_host_async", "rvo_wait_upload", "rvo_host_alloc", "rvo_host_free", "rvo_get_descriptors", "rvo_get_matches", "rvo_get_match_tracks", "rvo_get_match_consistency", "rvo_get_keypoint_tracks", "rvo_reset_tracks", "rvo_get_lut", "rvo_profile_enable", "rvo_profile_select", "rvo_profile_read",
     "rvo_selftest_stdalgo", "rvo_bgr_to_gray_dev", "rvo_depth_to_point_cloud_dev", "rvo_get_pair_information", "rvo_get_pair_information_noalloc", "rvo_set_pair_chunks", "rvo_wait_peer",
     "rvo_streams_record", "rvo_streams_set_source_index", "rvo_streams_depth_in_place", "rvo_trajectories_dev", "rvo_get_trajectories",
     "rvo_set_pipeline", "rvo_get_batch_results", "rvo_comm_get_unique_id", "rvo_comm_create", "rvo_comm_destroy", "rvo_gather_trajectories",
@@ -133,6 +133,7 @@ def load():
     L.rvo_get_descriptors.argtypes = [vp, ip, ip, vp]
     L.rvo_get_matches.argtypes = [vp, ip, ip, vp, vp]
     L.rvo_get_match_tracks.argtypes = [vp, ip, ip, vp]
+    L.rvo_get_match_consistency.argtypes = [vp, ip, ip, vp]
     L.rvo_stream_step_host_async.argtypes = [vp, ip, vp, vp]
     L.rvo_wait_upload.argtypes = [vp]
     L.rvo_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]

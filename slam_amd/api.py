@@ -231,6 +231,14 @@ class Context:
             self._chk(rc)
         return out
 
+    def match_consistency(self, pair, n):
+        """FeatureMatch::consistency_vec of the rows matches(pair, n) returns: [n, n] u8, column = the other match's id."""
+        out = np.zeros((n, n), np.uint8)
+        rc = self.L.rvo_get_match_consistency(self.h, pair, n * n, _ptr(out))
+        if rc < 0:
+            self._chk(rc)
+        return out
+
     def keypoint_tracks(self, slot, level):
         """KeypointData::track_id of a level's keypoints (-1 = none)."""
         out = np.zeros(self.level_info(slot, level)["num_keypoints"], np.int32)

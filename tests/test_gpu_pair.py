@@ -32,6 +32,10 @@ def compare_pair(ctx, orc, pair, rg, ro, exact_dbl=True):
     if exact_dbl:
         assert np.array_equal(dg[:, :7], do[:, :7], equal_nan=True), "refined uv / rect / xyz differ"
     np.testing.assert_allclose(dg[:, 7], do[:, 7], rtol=0, atol=1e-7)
+    if 0 < n <= 1200:  # FeatureMatch::consistency_vec + compatibility_degree (feature.hpp:262-270), the whole N x N relation
+        cg, co = ctx.match_consistency(pair, n), orc.match_consistency(n)
+        assert np.array_equal(cg, co), "consistency vectors differ"
+        assert np.array_equal(cg.sum(1), ig[:, 6]) and not cg[np.arange(n), ig[:, 5]].any()
     assert np.abs(rg["pose"][:, 3] - ro["pose"][:, 3]).max() < POSE_TOL
     assert rot_angle(rg["pose"][:, :3], ro["pose"][:, :3]) < 1e-7  # arccos near 1 has ~1e-8 resolution
     assert np.abs(rg["pose"] - ro["pose"]).max() < POSE_TOL

@@ -392,3 +392,37 @@ def test_depth_read_in_place_equals_the_copying_step(scene, intr640):
         ctx.close()
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
     assert (out[0][0][:, 1:, 12] == 1).all()
+
+
+def test_configs0_full_sequence_300_frames_with_the_reference_warm_up(intr640):
+    """BASELINE configs[0] as a parity test (bench.py's cpu_baseline_sequence leg times the same thing): one 300-frame 640x480
+    stream through RGBDVO::ProcessFrame with the reference's own 100-frame warm-up (vo.cpp:58-69: 99 calls return at once,
+    the adaptive FAST threshold does not move during them), then 200 estimates; every frame's return code, threshold,
+    keyframe decision, status, match / inlier counts equal OracleVO's, poses to 1e-8, and the trajectory ends near the
+    ground truth."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.pyoracle import Oracle, OracleVO, default_params as odef
+    from slam_amd.api import RGBDVOStreams
+    n = 300
+    poses, _ = synth.sequence_poses(n, 0)
+    sc = synth.PlaneScene()
+    with ThreadPoolExecutor(8) as ex:  # numpy releases the GIL in the big array operations
+        frames = list(ex.map(lambda T: sc.render(intr640, T, 0.0, None), poses))
+    vo = RGBDVOStreams(intr640, 1)  # default options: warm-up 100
+    ovo = OracleVO(Oracle(intr640, odef()))
+    first = None
+    for i, (g, d) in enumerate(frames):
+        rg = vo.ProcessFrame(g[None], d[None])[0]
+        ro = ovo.process(g, d)
+        assert (rg["rc"], rg["fast_thr"], rg["keyframe_changed"]) == (ro["rc"], ro["fast_thr"], ro["keyframe_changed"]), i
+        if ro["rc"] == 1 and first is None:
+            first = i
+        if first is not None and i > first:
+            assert (rg["status"], rg["num_matches"], rg["num_inliers"], rg["used_fallback"]) == (ro["status"], ro["num_matches"], ro["num_inliers"], ro["used_fallback"]), i
+            assert rg["status"] == 1, i
+        assert np.abs(rg["pose"] - ro["pose"]).max() < 1e-8, i
+    assert first == 99
+    gt = np.linalg.inv(poses[first]) @ poses[-1]
+    assert np.abs(rg["pose"] - gt[:3]).max() < 2e-2
+    ovo.close()
+    vo.ctx.close()
