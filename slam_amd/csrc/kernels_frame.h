@@ -764,6 +764,13 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
   __syncthreads();
   FAST_PHASE(4);  // compaction
 
+  // the descriptor phase's tap table (below) is fetched now: its latency passes behind the nth_element replay instead of
+  // stalling the workgroup's last phase
+  uint32_t tapw[5] = {0u, 0u, 0u, 0u, 0u};
+  if (TPC) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) tapw[q] = kDescTaps<TPC ? TPC : 4>.w[tid & 7][q];
+  }
   // ---- GridKeyPointFilter::Filter for this bucket (pyramid.cpp:38-50)
   const int n = min(total, L.list_cap);
   const int maxp = g.max_per;
@@ -795,7 +802,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     if (TPC) {
 #pragma unroll
       for (int q = 0; q < 5; q++) {
-        const uint32_t w = kDescTaps<TPC ? TPC : 4>.w[sub][q];
+        const uint32_t w = tapw[q];
         toff[2 * q] = (int)(short)(w & 0xFFFFu);
         toff[2 * q + 1] = (int)w >> 16;
       }
