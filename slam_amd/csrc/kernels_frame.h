@@ -789,6 +789,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     fb.bk_cnt[(size_t)slot * g.total_buckets + gb] = keep;
     fb.bk_det[(size_t)slot * g.total_buckets + gb] = total;
   }
+  FAST_PHASE(6);  // bucket list written
   // ---- descriptors of the kept keypoints (ExtractAlignedDescriptor + Normalized twice, feature.cpp:6140-6156,
   // 6193-6207) straight from the LDS tile: the 9x9 window of a keypoint of this cell lies inside the cell + 4 px halo.
   // 8 lanes per keypoint, so the default 25 kept keypoints are one pass of the 32 groups: lane l owns descriptor dwords
@@ -848,7 +849,6 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
       reinterpret_cast<uint16_t*>(dsc)[32 + sub] = (uint16_t)__builtin_amdgcn_perm(0u, hb(P[4]), 0x0C0C0301u);
     }
   }
-  FAST_PHASE(6);  // lists + descriptors (thread 0's share)
 }
 
 // ------------------------------------------------------------------ keypoint records + XYZ

@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 def _cases():
     rng = np.random.default_rng(42)
     out = []
-    for t in range(160):
-        n = int(rng.integers(1, 1800)) if t % 8 else int(rng.integers(2000, 8000))
+    for t in range(280):
+        # 160 general sizes, then 120 small ones (4..200: the ranges the three-round-trip partition of round 3 takes)
+        n = (int(rng.integers(1, 1800)) if t % 8 else int(rng.integers(2000, 8000))) if t < 160 else int(rng.integers(4, 200))
         spread = [3, 30, 250, n][t % 4]
         if t % 11 == 0:
             k = np.arange(n) % max(1, spread)            # sawtooth

@@ -22,11 +22,11 @@ intr = synth.default_intrinsics(640, 480)
 ctx = Context(intr, default_params(frame_matcher=True), max_frames=2 * n_pairs, max_pairs=n_pairs, device=0)
 slots = np.arange(2 * n_pairs, dtype=np.int32)
 L = _lib.load()
-names = ["stage", "phaseA", "phaseB", "nms", "compact", "nth", "lists+desc"]
+names = ["stage", "phaseA", "phaseB", "nms", "compact", "nth", "lists"]
 import time
 REPS = int(os.environ.get('EXP_REPS', '20'))
 have_abl = hasattr(L, "rvo_debug_fast_stop")  # only in -DRVO_PHASE_TIMING builds
-for stop in ((0, 1, 2, 3, 4, 5, 99) if have_abl else (99,)):  # ablation: k_fast_grid returns after phase `stop`; wall time of the whole prepare call
+for stop in ((0, 1, 2, 3, 4, 5, 6, 99) if have_abl else (99,)):  # ablation: k_fast_grid returns after phase `stop`; wall time of the whole prepare call
     if have_abl:
         L.rvo_debug_fast_stop(stop)
     for _ in range(3):
