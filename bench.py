@@ -486,7 +486,7 @@ def main():
                         launches_timed=prof_dom[dom]["calls"],
                         algorithmic_bytes_per_launch=B[dom],
                         note="launch = one whole batch (512 frames / 256 pairs); the launches of four batches are in flight at a time, "
-                             "so a launch's duration includes contention (0.30 ms alone); the kernel is VALU-bound, not "
+                             "so a launch's duration includes contention (0.285 ms alone); the kernel is VALU-bound, not "
                              "HBM-bound (DESIGN.md section 5); dominant = largest VALU issue time per batch")
         # VALU issue roofline (the bound that actually holds for this path): issue time per batch from
         # the committed SQ counters of this same command (a --pmc pass of its own) against the live batch time
@@ -601,7 +601,8 @@ def main():
             legs["configs4"]["workload"] = ("configs[4]: adversarial 640x480 pairs (texture contrast 0.12 = about 5 grey levels, 30 % of the depth "
                                             "invalid in blobs and salt noise, FAST threshold at its floor 5), 256 pairs per batch")
             legs["configs2_per_gpu"]["workload"] = ("configs[2] per-GPU shard: 512 lock-step 640x480 streams through rvo_stream_step_dev on one "
-                                                    "context, 16 distinct sequences replayed, device-resident inputs")
+                                                    "context, 16 distinct sequences replayed through rvo_streams_set_source_index, device-resident inputs, "
+                                                    "depth sampled in place (rvo_streams_depth_in_place)")
         line = dict(metric="frame-pairs/sec (whole node) at 640x480", value=value, unit="frame-pairs/s",
                     n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u8/int32/f64", data="synthetic",
