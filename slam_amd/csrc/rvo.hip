@@ -219,7 +219,8 @@ static int scratch_for_device(int device) {
 }
 
 #ifdef RVO_SKIP_EXPERIMENT  // one-off builds: RVO_SKIP=<kernel names> drops those launches, results go stale (what do they cost the pipeline?)
-#define RVO_SKIPPED(NAME) ((c)->batch_id > 12 && getenv("RVO_SKIP") && strstr(getenv("RVO_SKIP"), NAME) != nullptr)  // after every slot set has been filled once
+// whole names of a comma-separated list ("refine" does not name refine_finish); after every slot set has been filled once
+#define RVO_SKIPPED(NAME) ((c)->batch_id > 12 && getenv("RVO_SKIP") && (std::string(",") + getenv("RVO_SKIP") + ",").find(std::string(",") + NAME + ",") != std::string::npos)
 #else
 #define RVO_SKIPPED(NAME) false
 #endif
