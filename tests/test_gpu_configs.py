@@ -61,3 +61,38 @@ def test_pair_pipeline_unusual_configs(scene, size, over, thr, why):
         assert max(r["num_matches"] for r in rb) > 1024, [r["num_matches"] for r in rb]
     a.close()
     b.close()
+
+
+def test_largest_frame_the_pair_kernels_hold_and_the_first_one_beyond(scene):
+    """Maximum sizes: 1600x1200 with the default 80x80 grid is 400 buckets = 10 000 keypoint slots per frame, the most whose
+    sort keys + scratch fit the 160 KB of LDS k_clique works in (clique_lds_bytes, kernels_pair.h); one more column of
+    buckets is refused by rvo_create with RVO_E_UNSUPPORTED and a message instead of a launch failure later."""
+    import ctypes as C
+    import torch
+    from oracle.pyoracle import Oracle, default_params as odef
+    from slam_amd import _lib
+    from slam_amd.api import Context, default_params
+    W, H, thr = 1600, 1200, 10
+    intr = synth.default_intrinsics(W, H)
+    p = synth.make_pair(901, intr, scene)
+    gray, depth = np.stack([p[0], p[2]]), np.stack([p[1], p[3]])
+    orc = Oracle(intr, odef(frame_matcher=True))
+    orc.prepare(0, gray[0], depth[0], thr)
+    orc.prepare(1, gray[1], depth[1], thr)
+    ro = orc.match_pair(0, 1)
+    assert ro["status"] == 1 and ro["num_matches"] > 2048  # beyond k_clique_walk's register rows: the walk inside k_clique
+    ctx = Context(intr, default_params(frame_matcher=True), max_frames=2, max_pairs=1)
+    dg, dd = torch.from_numpy(gray).cuda(), torch.from_numpy(depth.view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    ctx.match_frames_dev(dg.data_ptr(), dd.data_ptr(), thr, np.arange(2))
+    compare_pair(ctx, orc, 0, ctx.pair_results(1)[0], ro)
+    ctx.close()
+    # 1680x1200: 21 x 15 + 11 x 8 + 6 x 4 = 427 buckets
+    L = _lib.load()
+    intr2 = synth.default_intrinsics(1680, 1200)
+    i2 = _lib.Intrinsics(**{k: intr2[k] for k, _ in _lib.Intrinsics._fields_})
+    prm = default_params(frame_matcher=True)
+    h = C.c_void_p()
+    rc = L.rvo_create(C.byref(i2), C.byref(prm), 0, 2, 1, C.byref(h))
+    assert rc == -2 and h.value is None, rc  # RVO_E_UNSUPPORTED
+    assert b"LDS" in L.rvo_last_error()
