@@ -102,7 +102,11 @@ void rvo_default_fm_params(rvo_params* out);
 
 /* Replaces the constructors RGBDVO::RGBDVO (rgbdvo/vo.cpp:22-47) and FrameMatcher::FrameMatcher
  * (rgbdvo/fm.cpp:6-20): builds the undistortion LUT (Camera::MakeXYMap, rgbdvo/camera.cpp:16-67) with one device
- * kernel (a host copy is kept for rvo_get_lut) and allocates `max_frames` frame slots and `max_pairs` pair work areas on `device`. */
+ * kernel (a host copy is kept for rvo_get_lut) and allocates `max_frames` frame slots and `max_pairs` pair work areas on `device`.
+ * RVO_E_UNSUPPORTED (with a message in rvo_last_error) for what this build does not hold: feature-window-size other than
+ * 9, more than 6 pyramid levels, images beyond 2047 x 2047 or below 32 x 32, a coarsest level under 24 px, grid cells
+ * below 8 px or too large for the LDS tile, more than 65535 keypoint slots per frame, and -- with max_pairs > 0 -- more
+ * keypoint slots per frame than the LDS-resident pair kernels sort (about 10 000: 1600 x 1200 at the default grid). */
 int rvo_create(const rvo_intrinsics* intr, const rvo_params* params, int device, int max_frames, int max_pairs,
                rvo_ctx** out);
 void rvo_destroy(rvo_ctx* ctx);
