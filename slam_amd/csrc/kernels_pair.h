@@ -685,8 +685,9 @@ __global__ __launch_bounds__(REFINE_THREADS, REFINE_MIN_WAVES) void k_refine(Fra
 #pragma unroll
   for (int m = 0; m < REFINE_TAPS; m++) toff[m] = desc_off(gl + REFINE_GROUP * m, S);
   // the four bilinear neighbours of a tap; the first three are also the taps of the target gradient at the same
-  // integer position (motion_estimate.cpp:800-815), so an accepted step needs no further loads for the next one
-  struct Nb { int p00, p01, p10; };
+  // integer position (motion_estimate.cpp:800-815), so an accepted step needs no further loads for the next one: kept as
+  // the two differences (p01 - p00, p10 - p00), an i16 pair in one register
+  typedef s2_t Nb;
   uint8_t* win = s_win[threadIdx.x / REFINE_GROUP];
   int ox, oy, xa;  // window = columns ox..ox+15, rows oy..oy+15; xa = aligned column the stored rows start at
   auto stage = [&](int cx, int cy) {  // window centred on (cx, cy); uniform per 16-lane group
@@ -720,23 +721,24 @@ __global__ __launch_bounds__(REFINE_THREADS, REFINE_MIN_WAVES) void k_refine(Fra
   };
   auto interp = [&](const Wts& w, int m, Nb& nb) -> int {
     const uint8_t* q = win + (w.v - oy) * REFINE_WIN_PITCH + (w.u - xa) + woff[m];
-    nb.p00 = q[0]; nb.p01 = q[1]; nb.p10 = q[REFINE_WIN_PITCH];
-    const float f = ((w.wa * (float)nb.p00 + w.wb * (float)nb.p01) + w.wc * (float)nb.p10) + w.wd * (float)q[REFINE_WIN_PITCH + 1];
+    const int p00 = q[0], p01 = q[1], p10 = q[REFINE_WIN_PITCH];
+    nb = s2_t{(short)(p01 - p00), (short)(p10 - p00)};
+    const float f = ((w.wa * (float)p00 + w.wb * (float)p01) + w.wc * (float)p10) + w.wd * (float)q[REFINE_WIN_PITCH + 1];
     return (int)f;
   };
   const int rbase = kp_y(rkp) * S + kp_x(rkp);
   const float tu = (float)kp_x(tkp), tv = (float)kp_y(tkp);
   float tx = tu, ty = tv;
   Wts wt = make_wts(tx, ty, S);
-  int rraw[REFINE_TAPS], rdx[REFINE_TAPS], rdy[REFINE_TAPS], traw[REFINE_TAPS];
+  int rraw[REFINE_TAPS], traw[REFINE_TAPS];
+  s2_t rd[REFINE_TAPS];  // reference gradient taps (dx, dy), |values| <= 255
   Nb tnb[REFINE_TAPS];
   int rsum = 0, tsum = 0;
 #pragma unroll
   for (int m = 0; m < REFINE_TAPS; m++) {
     const int kr = rbase + toff[m];
     rraw[m] = gload<uint8_t>(rg + kr);
-    rdx[m] = gload<uint8_t>(rg + kr + 1) - rraw[m];
-    rdy[m] = gload<uint8_t>(rg + kr + S) - rraw[m];
+    rd[m] = s2_t{(short)(gload<uint8_t>(rg + kr + 1) - rraw[m]), (short)(gload<uint8_t>(rg + kr + S) - rraw[m])};
     traw[m] = interp(wt, m, tnb[m]);
     rsum += rraw[m];
     tsum += traw[m];
@@ -749,27 +751,38 @@ __global__ __launch_bounds__(REFINE_THREADS, REFINE_MIN_WAVES) void k_refine(Fra
   struct P5 { s2_t a, b; int c; };
   auto pack5 = [](const int* v) { P5 p; p.a = s2_t{(short)v[0], (short)v[1]}; p.b = s2_t{(short)v[2], (short)v[3]}; p.c = v[4]; return p; };
   auto dot5 = [](const P5& x, const P5& y) { return __builtin_amdgcn_sdot2(x.a, y.a, __builtin_amdgcn_sdot2(x.b, y.b, x.c * y.c, false), false); };
-  int rn[REFINE_TAPS];
-  P5 te;  // te = error of the current target descriptor against the reference's
+  P5 rn;  // the reference's normalised descriptor taps (0..255), in dot5's pair layout
   {
-    int e[REFINE_TAPS];
+    int v[REFINE_TAPS];
 #pragma unroll
-    for (int m = 0; m < REFINE_TAPS; m++) {
-      rn[m] = norm_px(rraw[m], rmean);
-      e[m] = norm_px(traw[m], tmean) - rn[m];
-    }
-    te = pack5(e);
+    for (int m = 0; m < REFINE_TAPS; m++) v[m] = norm_px(rraw[m], rmean);
+    rn = pack5(v);
   }
+  // error of a target descriptor (raw taps, their mean) against the reference's: one packed subtraction per pair of taps
+  auto err5 = [&](const int* raw, int mean) {
+    int v[REFINE_TAPS];
+#pragma unroll
+    for (int m = 0; m < REFINE_TAPS; m++) v[m] = norm_px(raw[m], mean);
+    P5 e = pack5(v);
+    e.a -= rn.a; e.b -= rn.b; e.c -= rn.c;
+    return e;
+  };
+  P5 te = err5(traw, tmean);  // te = error of the current target descriptor against the reference's
   int final_sse = group16_sum(dot5(te, te));
   const int min_xy = RVO_WIN, max_x = G.w - RVO_WIN - 2, max_y = G.h - RVO_WIN - 2;  // pyramid.cpp:123-126
   for (int it = 0; it < 6; it++) {
-    int mxv[REFINE_TAPS], myv[REFINE_TAPS];
+    // mean gradient taps (x, y) of the five taps, one packed add each; then the x halves and the y halves gathered into
+    // the pair layout of dot5 (two v_perm per pair of taps)
+    uint32_t mw[REFINE_TAPS];
 #pragma unroll
-    for (int m = 0; m < REFINE_TAPS; m++) {
-      mxv[m] = rdx[m] + (tnb[m].p01 - tnb[m].p00);
-      myv[m] = rdy[m] + (tnb[m].p10 - tnb[m].p00);
-    }
-    const P5 mx = pack5(mxv), my = pack5(myv);
+    for (int m = 0; m < REFINE_TAPS; m++) mw[m] = __builtin_bit_cast(uint32_t, (s2_t)(rd[m] + tnb[m]));
+    P5 mx, my;
+    mx.a = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm(mw[1], mw[0], 0x05040100u));
+    mx.b = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm(mw[3], mw[2], 0x05040100u));
+    mx.c = (int)(short)(mw[4] & 0xFFFFu);
+    my.a = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm(mw[1], mw[0], 0x07060302u));
+    my.b = __builtin_bit_cast(s2_t, __builtin_amdgcn_perm(mw[3], mw[2], 0x07060302u));
+    my.c = (int)mw[4] >> 16;
     const int S00 = group16_sum(dot5(mx, mx)), S01 = group16_sum(dot5(mx, my)), S11 = group16_sum(dot5(my, my));
     const int gxs = group16_sum(dot5(mx, te)), gys = group16_sum(dot5(my, te));
     const double s00 = S00, s01 = S01, s11 = S11;
@@ -796,10 +809,7 @@ __global__ __launch_bounds__(REFINE_THREADS, REFINE_MIN_WAVES) void k_refine(Fra
 #pragma unroll
     for (int m = 0; m < REFINE_TAPS; m++) { nraw[m] = interp(wn, m, nnb[m]); nsum += nraw[m]; }
     const int nmean = group16_sum(nsum) / RVO_DESC_LEN;
-    int nev[REFINE_TAPS];
-#pragma unroll
-    for (int m = 0; m < REFINE_TAPS; m++) nev[m] = norm_px(nraw[m], nmean) - rn[m];
-    const P5 ne = pack5(nev);
+    const P5 ne = err5(nraw, nmean);
     const int sse = group16_sum(dot5(ne, ne));
     if (sse < final_sse) {
       tx = ntx; ty = nty; final_sse = sse;
