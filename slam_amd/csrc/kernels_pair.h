@@ -140,6 +140,24 @@ __device__ inline uint32_t wave_min_u(uint32_t v) {
   return v;
 }
 
+// sum over the 64 lanes of a wave on the DPP network (no LDS crossbar); the total is valid in lane 63.  Fixed order.
+template <int CTRL, int ROW_MASK>
+__device__ inline double rot_dpp_add(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+  return v + __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+__device__ inline double rot_wave_sum63(double v) {
+  v = rot_dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = rot_dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = rot_dpp_add<0x141, 0xF>(v);  // row_half_mirror
+  v = rot_dpp_add<0x140, 0xF>(v);  // row_mirror: every lane of a row holds the row's sum
+  v = rot_dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v = rot_dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // sum N doubles per thread over a 256-thread block; result valid in every thread. s_red: N*4 doubles.
 template <int N>
 __device__ inline void block_sum_d(double* v, double* s_red) {
@@ -219,6 +237,7 @@ __global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs 
   float* tdy = tdx + npx;
   float* warped = tdy + npx;
   double* s_red = reinterpret_cast<double*>(lds + (((size_t)5 * npx * 4 + 15) & ~(size_t)15));
+  float* s_ctl = reinterpret_cast<float*>(s_red + 40);  // next homography [9] and the stop flag, written by wave 0 (s_red: 64 doubles)
 
   const uint8_t* rimg = level_img(fb, g, pb.rot_slot[pair], pyr);
   const uint8_t* timg = level_img(fb, g, pb.tgt_slot[pair], pyr);
@@ -254,7 +273,7 @@ __global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs 
   double minError = INFINITY, lastRMS = INFINITY;
   int bestIter = 0, lastImproved = 0;
   for (int iter = 0; iter < 8; iter++) {
-    __syncthreads();
+    // (no barrier here: the two at the end of an iteration separate its reads of `warped` from the writes below)
     // constructWarpedImage, :1538-1571
     for (int i = tid; i < npx; i += 256) {
       const int y = div_u16(i, cols), x = i - y * cols;
@@ -294,8 +313,18 @@ __global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs 
       acc[6] += J0 * E; acc[7] += J1 * E; acc[8] += J2 * E;
       acc[9] += E * E;
     }
-    block_sum_d<10>(acc, s_red);
-    // everything below is computed identically by every thread
+    // the waves' sums on the DPP network (total in lane 63), then wave 0 alone adds the four partials, solves and steps:
+    // the solve is a chain of fp64 divisions and sin / cos that every thread used to repeat (most of the kernel's
+    // instructions, on all four waves); the others pick the next homography and the stop flag up from LDS
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      const double sk = rot_wave_sum63(acc[k]);
+      if ((tid & 63) == 63) s_red[k * 4 + (tid >> 6)] = sk;
+    }
+    __syncthreads();
+    if (tid < 64) {  // computed identically by every lane of wave 0
+#pragma unroll
+    for (int k = 0; k < 10; k++) acc[k] = ((s_red[k * 4] + s_red[k * 4 + 1]) + s_red[k * 4 + 2]) + s_red[k * 4 + 3];
     const double rms = sqrt(acc[9]) / sqrt((double)npx);
     if (rms < minError) { minError = rms; for (int k = 0; k < 9; k++) bestH[k] = H[k]; bestIter = iter; }
     const double A00 = acc[0], A01 = acc[1], A02 = acc[2], A11 = acc[3], A12 = acc[4], A22 = acc[5];
@@ -318,12 +347,21 @@ __global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs 
     float Hn[9];
     for (int r = 0; r < 3; r++)
       for (int c = 0; c < 3; c++) Hn[r * 3 + c] = (H[r * 3] * E[c] + H[r * 3 + 1] * E[3 + c]) + H[r * 3 + 2] * E[6 + c];
-    for (int k = 0; k < 9; k++) H[k] = Hn[k];
     if (rms < lastRMS) lastImproved = iter;
     const float l0 = (float)lie[0], l1 = (float)lie[1], l2 = (float)lie[2];
     const double lnorm = sqrt((double)(l0 * l0 + l1 * l1 + l2 * l2));
-    if (lnorm < 1e-6 || (rms - minError > 3 && iter - bestIter > 2) || iter - bestIter > 4 || iter - lastImproved > 2) break;
+    const bool stop = lnorm < 1e-6 || (rms - minError > 3 && iter - bestIter > 2) || iter - bestIter > 4 || iter - lastImproved > 2;
     lastRMS = rms;
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) s_ctl[k] = Hn[k];
+      s_ctl[9] = stop ? 1.f : 0.f;
+    }
+    }
+    __syncthreads();
+    if (s_ctl[9] != 0.f) break;
+#pragma unroll
+    for (int k = 0; k < 9; k++) H[k] = s_ctl[k];
   }
   if (tid == 0) {
     const double sf = (double)(1 << irl);
