@@ -129,17 +129,6 @@ __device__ inline double dot4(const double* r, double x, double y, double z, dou
   return ((r[0] * x + r[1] * y) + r[2] * z) + r[3] * w;
 }
 
-__device__ inline double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ inline uint32_t wave_min_u(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
-  return v;
-}
-
 // sum over the 64 lanes of a wave on the DPP network (no LDS crossbar); the total is valid in lane 63.  Fixed order.
 template <int CTRL, int ROW_MASK>
 __device__ inline double rot_dpp_add(double v) {
@@ -156,63 +145,6 @@ __device__ inline double rot_wave_sum63(double v) {
   v = rot_dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
   v = rot_dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
   return v;
-}
-
-// sum N doubles per thread over a 256-thread block; result valid in every thread. s_red: N*4 doubles.
-template <int N>
-__device__ inline void block_sum_d(double* v, double* s_red) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    const double s = wave_sum_d(v[i]);
-    if (lane == 0) s_red[i * 4 + wid] = s;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < N; i++) v[i] = ((s_red[i * 4] + s_red[i * 4 + 1]) + s_red[i * 4 + 2]) + s_red[i * 4 + 3];
-}
-
-// Same sum for the latency-bound single-block kernels: N values per thread are parked in LDS ([N][256] doubles),
-// N*8 threads add 32 of them each (rotated start: lanes hit different banks), thread 0 adds the 8 partials.
-// Fixed order, so results are deterministic.  Result valid in thread 0 only.  s_big: N*256 + N*16 doubles; NT >= N*16.
-// NT = block size (multiple of 256).
-template <int N, int NT>
-__device__ inline void block_sum_lds(double* v, double* s_big) {
-  const int tid = threadIdx.x;
-  double* s_part = s_big + N * 256;
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < NT / 256; q++) {  // threads t, t+256, ... fold into slot t one after the other
-    if ((tid >> 8) == q) {
-#pragma unroll
-      for (int i = 0; i < N; i++) {
-        if (q == 0) s_big[i * 256 + (tid & 255)] = v[i];
-        else s_big[i * 256 + (tid & 255)] += v[i];
-      }
-    }
-    __syncthreads();
-  }
-  if (tid < N * 16) {  // 16 threads per value, each folds 16 slots (rotated start: no bank conflicts)
-    const double* seg = s_big + tid * 16;
-    double s = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) s += seg[(j + tid) & 15];
-    s_part[tid] = s;
-  }
-  __syncthreads();
-  if (tid < N) {  // one thread per value folds its 16 partials; the front of s_big is free again
-    const double* q = s_part + tid * 16;
-    double s = q[0];
-#pragma unroll
-    for (int j = 1; j < 16; j++) s += q[j];
-    s_big[tid] = s;
-  }
-  __syncthreads();
-  if (tid == 0) {
-#pragma unroll
-    for (int i = 0; i < N; i++) v[i] = s_big[i];
-  }
 }
 
 // ------------------------------------------------------------------ initial rotation
