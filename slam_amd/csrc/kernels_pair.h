@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256, ROT_MIN_WAVES) void k_init_rotation(FrameBufs 
       acc[9] += E * E;
     }
     // the waves' sums on the DPP network (total in lane 63), then wave 0 alone adds the four partials, solves and steps:
-    // the solve is a chain of fp64 divisions and sin / cos that every thread used to repeat (most of the kernel's
-    // instructions, on all four waves); the others pick the next homography and the stop flag up from LDS
+    // the solve is a chain of fp64 divisions and sin / cos that every thread used to repeat (a fifth of the kernel's
+    // instructions); the others pick the next homography and the stop flag up from LDS
 #pragma unroll
     for (int k = 0; k < 10; k++) {
       const double sk = rot_wave_sum63(acc[k]);
