@@ -2,7 +2,7 @@
 // final status (rgbdvo/motion_estimate.cpp:198-232, 610-720, 1208-1331).  Included by kernels_pair.h.
 //
 // One workgroup of 256 threads (one wave per SIMD) per pair; 168 VGPRs and 7.3 KB of LDS with the inlier list: what seven
-// k_fast_grid workgroups (48 VGPRs, 22 KB each) leave free on a CU, so a workgroup of this latency-bound kernel is placed
+// k_fast_grid workgroups (39 VGPRs, 22 KB each) leave free on a CU, so a workgroup of this latency-bound kernel is placed
 // without waiting for FAST workgroups to retire.
 //
 // refineMotionEstimateBidirectional (:1208-1331) evaluates, per iteration, the Jacobian at the current parameters and
