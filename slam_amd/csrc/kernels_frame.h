@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
     if (l < g.levels && gb >= g.lv[l].bucket_off) lvl = l;
   const LevelGeom G = g.lv[lvl];
   const int bi = gb - G.bucket_off;
-  const int brow = (int)__umulhi((uint32_t)bi, kInv32.v[G.gcols]);  // bi / gcols (bi < 2^16, gcols <= 256)
+  const int brow = div_u16(bi, G.gcols);  // bi / gcols (bi < 2^16)
   const int cx0 = (bi - brow * G.gcols) * g.gw, cy0 = brow * g.gh;
   const int cw = min(g.gw, G.w - cx0), ch = min(g.gh, G.h - cy0);
   const uint8_t* __restrict__ img = level_img(fb, g, slot, lvl);
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_fast_grid(FrameBufs fb, FrameGeom g, Fa
       const int bit = __ffs(word) - 1;
       word &= word - 1;
       const int idx = (w << 5) + bit;
-      const int y = (int)__umulhi((uint32_t)idx, inv_cw), x = idx - y * cw;
+      const int y = (int)div_inv32((uint32_t)idx, cw, inv_cw), x = idx - y * cw;
       if (pos < L.list_cap) s_list[pos] = kp_pack(cx0 + x, cy0 + y, s_score[(y + 1) * SP + (x + 1)] - 1);
       pos++;
     }

@@ -129,16 +129,21 @@ static constexpr Inv16Table make_inv16() {
   return t;
 }
 __constant__ Inv16Table kInv16 = make_inv16();
-// floor((2^32 - 1) / n) + 1: idx / n == umulhi(idx, kInv32[n]) for idx < 2^16, n <= 2^8
+// floor((2^32 - 1) / n) + 1: idx / n == umulhi(idx, kInv32[n]) for idx < 2^16, 2 <= n <= 2^8.  n = 1 has no entry (2^32 does
+// not fit a word; the slot holds 0): every use goes through div_inv32 / div_u16, which take x / 1 = x themselves -- a level
+// one bucket wide, or one keypoint per bucket, once divided everything to 0 here (found by tools/fuzz_parity.py).
 static constexpr Inv16Table make_inv32() {
   Inv16Table t{};
   t.v[0] = 0;
-  for (int n = 1; n <= 256; n++) t.v[n] = 0xFFFFFFFFu / (uint32_t)n + 1u;
+  t.v[1] = 0;
+  for (int n = 2; n <= 256; n++) t.v[n] = 0xFFFFFFFFu / (uint32_t)n + 1u;
   return t;
 }
 __constant__ Inv16Table kInv32 = make_inv32();
+// x / n with inv = kInv32.v[n] fetched once (x < 2^16, 1 <= n <= 256)
+__device__ inline uint32_t div_inv32(uint32_t x, int n, uint32_t inv) { return n == 1 ? x : __umulhi(x, inv); }
 // x / n for a divisor that is uniform but only known at run time (x < 2^16)
-__device__ inline int div_u16(int x, int n) { return n <= 256 ? (int)__umulhi((uint32_t)x, kInv32.v[n]) : x / n; }
+__device__ inline int div_u16(int x, int n) { return n == 1 ? x : n <= 256 ? (int)__umulhi((uint32_t)x, kInv32.v[n]) : x / n; }
 
 
 // A pointer that was loaded from memory (the per-slot image / depth tables) is "generic" to the compiler, and accesses

@@ -23,6 +23,10 @@ CONFIGS = [
      "odd cells, one level (initial rotation on level 0), few keypoints per cell, harsh reprojection pruning"),
     ((362, 250), dict(grid_width=45, grid_height=40, max_keypoints_per_grid=10, num_pyramid_levels=3), 15,
      "odd level sizes (181x125 -> 90x62: the odd-length edge formulas of the pyramid in both directions)"),
+    ((396, 314), dict(grid_width=116, grid_height=27, max_keypoints_per_grid=7, num_pyramid_levels=4), 12,
+     "coarse levels ONE bucket wide and several high (99x78 -> 1 x 3 buckets: bucket row = index / 1; tools/fuzz_parity.py found it)"),
+    ((320, 240), dict(grid_width=40, grid_height=40, max_keypoints_per_grid=1, num_pyramid_levels=2, min_features_for_estimate=5), 10,
+     "one keypoint per bucket (bucket of a keypoint slot = slot / 1)"),
 ]
 
 
