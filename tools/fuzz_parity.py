@@ -29,8 +29,8 @@ def main():
     bad, pairs_done, succ, soft = 0, 0, 0, 0
     t0 = time.time()
     for c in range(n_cfg):
-        W = int(rng.integers(80, 330)) * 2
-        H = int(rng.integers(60, 250)) * 2
+        W = int(rng.integers(160, 660))  # odd sizes too: level strides, the pyramid's odd-length edge formulas
+        H = int(rng.integers(120, 500))
         levels = int(rng.integers(1, 5))
         while levels > 1 and min(W, H) >> (levels - 1) < 24:
             levels -= 1
@@ -42,8 +42,17 @@ def main():
                     min_features_for_estimate=int(rng.choice([5, 10, 20])))
         thr = int(rng.integers(5, 41))
         intr = synth.default_intrinsics(W, H)
+        kind = rng.random(4)
+        if kind[0] < 0.3:  # a distorted input camera: the undistortion LUT, keypoints that leave the rectified image
+            intr.update(k1=float(rng.uniform(-0.12, 0.12)), k2=float(rng.uniform(-0.02, 0.02)), p1=float(rng.uniform(-2e-3, 2e-3)),
+                        p2=float(rng.uniform(-2e-3, 2e-3)))
+        half_depth = kind[1] < 0.2  # depth image at half the resolution (Depth::x_scale_ / y_scale_, depth.cpp:14-15)
+        if half_depth:
+            intr.update(depth_width=W // 2, depth_height=H // 2)
+        host_path = kind[2] < 0.35    # rvo_prepare_frames + rvo_match_pairs on host buffers instead of the fused device call
+        with_init = kind[3] < 0.3     # EstimateMotion with a given initial estimate (the VO call form) instead of the initial rotation
         n = 3
-        tag = f"cfg {c}: {W}x{H} L{levels} grid {over['grid_width']}x{over['grid_height']}x{over['max_keypoints_per_grid']} thr {thr}"
+        tag = f"cfg {c}: {W}x{H}{' distorted' if intr['k1'] else ''}{' depth/2' if half_depth else ''}{' host' if host_path else ''}{' init' if with_init else ''} L{levels} grid {over['grid_width']}x{over['grid_height']}x{over['max_keypoints_per_grid']} thr {thr}"
         # every random draw of the configuration is made here, so that FUZZ_ONLY=<index> replays one configuration alone
         draws = [(int(rng.integers(0, 10 ** 6)), int(rng.integers(0, 3)), float(rng.choice([0.0, 0.1, 0.3])),
                   float(rng.choice([0.01, 0.03, 0.08])), float(rng.choice([0.3, 1.0, 3.0]))) for _ in range(n)]
@@ -60,19 +69,28 @@ def main():
             pairs = [synth.make_pair(sd, intr, scenes[sc], invalid_frac=inv, max_t=mt, max_rot_deg=mr) for sd, sc, inv, mt, mr in draws]
             gray = np.stack([p[j] for p in pairs for j in (0, 2)])
             depth = np.stack([p[j] for p in pairs for j in (1, 3)])
+            # (synth renders the depth image at the intrinsics' depth resolution)
+            assert gray.shape == (2 * n, H, W) and depth.shape == (2 * n, intr["depth_height"], intr["depth_width"])  # the device entry points trust their pointers
+            inits = None
+            if with_init:  # the true motion, slightly off
+                inits = np.stack([(p[4] @ synth.make_pose([0.004, -0.003, 0.002], [0.002, -0.001, 0.0015]))[:3] for p in pairs])
             if low_contrast:  # few, weak corners
                 gray = (128 + (gray.astype(np.float32) - 128) * 0.15).astype(np.uint8)
-            dg, dd = torch.from_numpy(gray).cuda(), torch.from_numpy(depth.view(np.int16)).cuda()
-            torch.cuda.synchronize()
-            ctx.match_frames_dev(dg.data_ptr(), dd.data_ptr(), thr, np.arange(2 * n))
-            rb = ctx.pair_results(n)
+            if host_path:
+                ctx.prepare_frames(gray, depth, thr, np.arange(2 * n))
+                rb = ctx.match_pairs(np.arange(0, 2 * n, 2), np.arange(1, 2 * n, 2), init_pose=inits)
+            else:
+                dg, dd = torch.from_numpy(gray).cuda(), torch.from_numpy(depth.view(np.int16)).cuda()
+                torch.cuda.synchronize()
+                ctx.match_frames_dev(dg.data_ptr(), dd.data_ptr(), thr, np.arange(2 * n), init_pose=inits)
+                rb = ctx.pair_results(n)
             st = []
             for i in range(n):
                 orc.prepare(0, gray[2 * i], depth[2 * i], thr)
                 orc.prepare(1, gray[2 * i + 1], depth[2 * i + 1], thr)
                 _compare_frame(ctx, orc, 2 * i, 0, levels)  # the frames first: a mismatch names its level and stage
                 _compare_frame(ctx, orc, 2 * i + 1, 1, levels)
-                ro = orc.match_pair(0, 1)
+                ro = orc.estimate_motion(0, 1, inits[i]) if with_init else orc.match_pair(0, 1)
                 try:
                     compare_pair(ctx, orc, i, rb[i], ro)
                 except AssertionError:
