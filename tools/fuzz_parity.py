@@ -22,9 +22,9 @@ from test_gpu_frame import _compare_frame  # noqa: E402
 from test_gpu_pair import compare_pair  # noqa: E402
 
 
-def main():
-    n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+def run(n_cfg: int, seed: int):
+    """-> (configurations with a mismatch, pairs compared, pairs with a tolerance-class difference only)"""
+    rng = np.random.default_rng(seed)
     scenes = [synth.PlaneScene(seed=s) for s in range(3)]
     bad, pairs_done, succ, soft = 0, 0, 0, 0
     t0 = time.time()
@@ -121,6 +121,11 @@ def main():
             ctx.close()
     print(f"{pairs_done} pairs compared ({succ} with status SUCCESS), {bad} configurations with a mismatch, "
           f"{soft} pairs beyond 1e-9 but within 1e-7 in tolerance-class values, {time.time() - t0:.0f} s")
+    return bad, pairs_done, soft
+
+
+def main():
+    bad, _, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     sys.exit(1 if bad else 0)
 
 
