@@ -146,7 +146,9 @@ int rvo_sync(rvo_ctx* ctx);
  * frame slots.  Host-buffer form (copies H2D, then runs, then synchronises). */
 int rvo_prepare_frames(rvo_ctx* ctx, int n, const uint8_t* gray, const uint16_t* depth, const int32_t* fast_thr,
                        const int32_t* slots);
-/* Same, gray/depth already in device memory; enqueues only (no synchronisation). */
+/* Same, gray/depth already in device memory; enqueues only (no synchronisation).  Like every entry point here it trusts its
+ * pointers: the buffers must hold n images of the sizes the context's intrinsics name (Wd x Hd for depth), a shorter one is
+ * read past its end by the GPU. */
 int rvo_prepare_frames_dev(rvo_ctx* ctx, int n, const uint8_t* gray_dev, const uint16_t* depth_dev,
                            const int32_t* fast_thr, const int32_t* slots);
 
