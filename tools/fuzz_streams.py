@@ -10,6 +10,7 @@ import time
 import traceback
 
 import numpy as np
+import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,7 +27,7 @@ def main():
     bad, steps_done, est, retried = 0, 0, 0, 0
     t0 = time.time()
     for c in range(n_cfg):
-        W, H = int(rng.integers(100, 330)) * 2, int(rng.integers(80, 250)) * 2
+        W, H = int(rng.integers(200, 660)), int(rng.integers(160, 500))  # odd sizes too (rows then are not 16-byte multiples: the copying ingest)
         levels = int(rng.integers(1, 5))
         while levels > 1 and min(W, H) >> (levels - 1) < 24:
             levels -= 1
@@ -40,7 +41,8 @@ def main():
         inval = [float(rng.choice([0.0, 0.1, 0.3])) for _ in range(n_streams)]
         # disturbances: (frame, stream, kind) -- a blank frame (no features) or a frame of another place (tracking lost)
         dist = {(int(rng.integers(warm + 1, n_frames)), int(rng.integers(0, n_streams))): int(rng.integers(0, 2)) for _ in range(int(rng.integers(0, 4)))}
-        tag = f"cfg {c}: {W}x{H} L{levels} grid {over['grid_width']}x{over['grid_height']}x{over['max_keypoints_per_grid']} warm {warm} streams {n_streams} groups {groups} frames {n_frames} disturbed {sorted(dist)}"
+        path = int(rng.integers(0, 3))  # 0: host buffers (rvo_stream_step), 1: device buffers, 2: device buffers with the depth images read in place
+        tag = f"cfg {c}: {W}x{H} {('host', 'dev', 'dev+depth in place')[path]} L{levels} grid {over['grid_width']}x{over['grid_height']}x{over['max_keypoints_per_grid']} warm {warm} streams {n_streams} groups {groups} frames {n_frames} disturbed {sorted(dist)}"
         if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != c:
             continue
         intr = synth.default_intrinsics(W, H)
@@ -48,6 +50,8 @@ def main():
         os.environ["RVO_STREAM_GROUPS"] = str(groups)
         try:
             vo = RGBDVOStreams(intr, n_streams, params=default_params(**over))
+            if path == 2:
+                vo.ctx.streams_depth_in_place(True)
         except Exception as e:
             print(tag, "-> refused:", str(e)[:80], flush=True)
             continue
@@ -67,7 +71,13 @@ def main():
                     gs.append(g); ds.append(d)
                 gray, depth = np.stack(gs), np.stack(ds)
                 assert gray.shape == (n_streams, H, W) and depth.shape == (n_streams, H, W)
-                res = vo.ProcessFrame(gray, depth)
+                if path == 0:
+                    res = vo.ProcessFrame(gray, depth)
+                else:  # device-resident images; with depth in place every step's buffers stay alive until the results are read
+                    dg, dd = torch.from_numpy(gray).cuda(), torch.from_numpy(depth.view(np.int16)).cuda()
+                    torch.cuda.synchronize()
+                    vo.ctx.stream_step_dev(dg.data_ptr(), dd.data_ptr(), n_streams)
+                    res = vo.ctx.stream_results(n_streams)
                 for s in range(n_streams):
                     ro, rg = ovos[s].process(gray[s], depth[s]), res[s]
                     where = (f, s)
