@@ -41,6 +41,9 @@ def run(n_cfg: int, seed: int):
                     inlier_max_reprojection_error=float(rng.choice([0.8, 1.5, 3.0])),
                     min_features_for_estimate=int(rng.choice([5, 10, 20])))
         thr = int(rng.integers(5, 41))
+        if os.environ.get("FUZZ_BIG"):  # many keypoints: more than 1024 / 2048 matches per pair (the clique kernels' other row regimes)
+            W, H, thr = int(rng.integers(500, 1000)), int(rng.integers(400, 760)), int(rng.integers(5, 16))
+            over.update(grid_width=int(rng.integers(24, 61)), grid_height=int(rng.integers(24, 61)), max_keypoints_per_grid=int(rng.integers(10, 41)))
         intr = synth.default_intrinsics(W, H)
         kind = rng.random(4)
         if kind[0] < 0.3:  # a distorted input camera: the undistortion LUT, keypoints that leave the rectified image
