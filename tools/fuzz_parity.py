@@ -44,6 +44,18 @@ def run(n_cfg: int, seed: int):
         if os.environ.get("FUZZ_BIG"):  # many keypoints: more than 1024 / 2048 matches per pair (the clique kernels' other row regimes)
             W, H, thr = int(rng.integers(500, 1000)), int(rng.integers(400, 760)), int(rng.integers(5, 16))
             over.update(grid_width=int(rng.integers(24, 61)), grid_height=int(rng.integers(24, 61)), max_keypoints_per_grid=int(rng.integers(10, 41)))
+        if os.environ.get("FUZZ_EXTREME"):  # the ends of the option ranges: tiny and huge cells, 1 or 100 keypoints per cell, thresholds
+            lv = int(rng.integers(1, 7))      # near 0 and far above the texture's contrast, up to 6 levels, tiny and huge search windows
+            while lv > 1 and min(W, H) >> (lv - 1) < 24:
+                lv -= 1
+            levels = lv
+            gsel = lambda: int(rng.integers(8, 24)) if rng.random() < 0.5 else int(rng.integers(121, 254))
+            over.update(grid_width=gsel(), grid_height=gsel(), num_pyramid_levels=lv,
+                        max_keypoints_per_grid=int(rng.choice([1, 2, 3, 50, 80, 120])),
+                        feature_search_window=float(rng.choice([1.0, 5.0, 100.0, 400.0])),
+                        min_features_for_estimate=int(rng.choice([6, 8, 50])))  # (with 1-3 inliers the 6-parameter normal equations are
+            # singular or nearly so: both sides then amplify their rounding without bound, poses differ by centimetres, nothing to compare)
+            thr = int(rng.choice([1, 2, 3, 4, 45, 60, 90, 120]))
         intr = synth.default_intrinsics(W, H)
         kind = rng.random(4)
         if kind[0] < 0.3:  # a distorted input camera: the undistortion LUT, keypoints that leave the rectified image
