@@ -72,6 +72,8 @@ def run(n_cfg: int, seed: int):
         draws = [(int(rng.integers(0, 10 ** 6)), int(rng.integers(0, 3)), float(rng.choice([0.0, 0.1, 0.3])),
                   float(rng.choice([0.01, 0.03, 0.08])), float(rng.choice([0.3, 1.0, 3.0]))) for _ in range(n)]
         low_contrast = rng.random() < 0.3
+        noise = rng.random() < 0.12   # images of (block) noise instead of the rendered scene: a corner candidate on almost every pixel
+        noise_seed, noise_block, noise_shift = int(rng.integers(0, 10 ** 6)), int(rng.choice([1, 1, 2, 3])), (int(rng.integers(-3, 4)), int(rng.integers(-3, 4)))
         if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != c:
             continue
         try:
@@ -84,6 +86,13 @@ def run(n_cfg: int, seed: int):
             pairs = [synth.make_pair(sd, intr, scenes[sc], invalid_frac=inv, max_t=mt, max_rot_deg=mr) for sd, sc, inv, mt, mr in draws]
             gray = np.stack([p[j] for p in pairs for j in (0, 2)])
             depth = np.stack([p[j] for p in pairs for j in (1, 3)])
+            if noise:  # FAST's candidate queue overflows into its dense pass, every bucket overflows, SAD scores tie: the second
+                nr = np.random.default_rng(noise_seed)  # frame of a pair is the first one shifted by a few pixels
+                for i in range(n):
+                    base = nr.integers(0, 256, ((H + noise_block - 1) // noise_block, (W + noise_block - 1) // noise_block), dtype=np.uint8)
+                    g0 = np.kron(base, np.ones((noise_block, noise_block), np.uint8))[:H, :W]
+                    gray[2 * i], gray[2 * i + 1] = g0, np.roll(g0, noise_shift, axis=(0, 1))
+                    depth[2 * i + 1] = np.roll(depth[2 * i], (noise_shift[0] * depth.shape[1] // H, noise_shift[1] * depth.shape[2] // W), axis=(0, 1))
             # (synth renders the depth image at the intrinsics' depth resolution)
             assert gray.shape == (2 * n, H, W) and depth.shape == (2 * n, intr["depth_height"], intr["depth_width"])  # the device entry points trust their pointers
             inits = None
@@ -127,7 +136,7 @@ def run(n_cfg: int, seed: int):
                 st.append((ro["status"], ro["num_matches"], ro["num_inliers"]))
                 pairs_done += 1
                 succ += ro["status"] == 1
-            print(tag, "->", st, flush=True)
+            print(tag + (" NOISE" if noise else ""), "->", st, flush=True)
         except AssertionError:
             bad += 1
             print(tag, "-> MISMATCH", flush=True)
